@@ -1,0 +1,146 @@
+/*
+ * mpcx.h -- C ABI of the MI355X (gfx950) batched MPC hot path.
+ *
+ * The reference (rdesarz/mpc-rs, crate `control_sys_rs`) has no FFI of its own: its boundary is the public Rust
+ * API in src/control/.  The entry points below are what a `-sys` crate for that API binds; each one names the
+ * reference function it replaces.  Everything is f64.  The library computes on the GPU only: there is no CPU
+ * path behind these calls, and a call fails (it never falls back) when no HIP device can be used.
+ *
+ * Conventions
+ *   - Return value: 0 = MPCX_OK; negative = argument error (MPCX_ERR_*); positive = hipError_t from the runtime.
+ *     Nothing unwinds or aborts across this boundary.  mpcx_last_error() gives the text of the last failure
+ *     of a context.
+ *   - A context is bound to one device and owns one stream plus staging buffers.  It is not thread-safe: use
+ *     one context per host thread (the reference's Controller holds an Rc and is !Send, controller.rs:3,8).
+ *     One process per GPU is the intended deployment; batches are sharded by instance index across processes.
+ *   - Host-pointer calls (no suffix) copy inputs to the device, run, copy the outputs back and return when the
+ *     outputs are in place.  `_dev` calls take device pointers and a hipStream_t (as void*), enqueue the work
+ *     and return without synchronising.  Callers own every buffer; the library keeps no pointer after return.
+ *   - Matrices of one instance are column-major, as nalgebra's DMatrix::as_slice() yields them: element (i, j)
+ *     of a rows x cols matrix has element index e = j*rows + i.
+ *   - Batch layout (`interleave`, W): element e of instance b of an array with E elements per instance lives at
+ *         (b / W) * (E * W)  +  e * W  +  (b % W).
+ *     W = 1 is instance-major (each instance's matrix contiguous: what a caller holding one DMatrix per plant
+ *     has).  W = 0 means W = batch (fully batch-interleaved, instance index fastest).  Any other W (a multiple
+ *     of 64) tiles the batch into groups of W instances; the last group is padded, so buffers hold
+ *     ceil(batch / W) * W * E elements.  One W applies to every per-instance array of a call.
+ *     Weights (W3, W4) are shared by the whole batch and are plain column-major matrices.
+ */
+#ifndef MPCX_H
+#define MPCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCX_VERSION 100 /* 0.1.0 */
+
+#define MPCX_OK 0
+#define MPCX_ERR_NULL (-1)        /* a required pointer is NULL */
+#define MPCX_ERR_DIMS (-2)        /* a dimension is out of range (n, m, r, f >= 1; 1 <= v <= f; batch, T >= 0) */
+#define MPCX_ERR_LAYOUT (-3)      /* interleave value not supported for these dimensions */
+#define MPCX_ERR_UNSUPPORTED (-4) /* combination of dimensions / modes exceeds what the kernels hold on chip */
+#define MPCX_ERR_NO_DEVICE (-5)   /* no usable HIP device */
+#define MPCX_ERR_SINGULAR (-6)    /* reported per instance through `info`, see mpcx_qp_gain_* */
+
+#define MPCX_INTERLEAVE_FULL 0 /* W = batch */
+#define MPCX_INTERLEAVE_AOS 1  /* W = 1, instance-major */
+
+#define MPCX_WEIGHTS_BLOCK 0 /* W4 = one r x r block, repeated on the diagonal of the (f r) x (f r) weight */
+#define MPCX_WEIGHTS_DENSE 1 /* W4 = dense (f r) x (f r), the argument of form_lifted_matrices (controller.rs:23) */
+
+#define MPCX_HESSIAN_AUTO 0       /* library picks */
+#define MPCX_HESSIAN_CONTRACT 1   /* H = Gamma^T (W4 Gamma) + W3 as a dense contraction (FP64 MFMA) */
+#define MPCX_HESSIAN_STRUCTURED 2 /* block-Toeplitz recurrence; needs MPCX_WEIGHTS_BLOCK */
+
+typedef struct mpcx_ctx mpcx_ctx;
+
+typedef struct mpcx_dims {
+    int32_t n; /* states:  A is n x n            (controller.rs:28) */
+    int32_t m; /* inputs:  B is n x m            (controller.rs:30) */
+    int32_t r; /* outputs: C is r x n            (controller.rs:29) */
+    int32_t f; /* prediction horizon             (controller.rs:20) */
+    int32_t v; /* control horizon, 1 <= v <= f   (controller.rs:21) */
+    int32_t weights_mode; /* MPCX_WEIGHTS_* */
+    int32_t hessian_algo; /* MPCX_HESSIAN_* */
+    int32_t u_shared;     /* rollout: 0 = U holds m x T per instance, 1 = one m x T shared by all instances */
+    int64_t batch;        /* number of independent instances */
+    int64_t T;            /* rollout: number of input columns (simulator.rs:10) */
+    int64_t interleave;   /* W, see above */
+} mpcx_dims;
+
+/* Fixed-size record of what a shard produced; ranks exchange these (not the results) after a sharded run. */
+typedef struct mpcx_stats {
+    int64_t count;      /* elements examined */
+    int64_t non_finite; /* NaN or Inf among them */
+    double sum;         /* sum of the elements */
+    double sum_sq;      /* sum of squares (squared Frobenius norm) */
+    double max_abs;     /* largest magnitude */
+    uint64_t checksum;  /* order-independent 64-bit checksum of the bit patterns (sum of mixed words) */
+} mpcx_stats;
+
+int mpcx_version(void);
+
+/* Number of f64 elements a per-instance array of E elements occupies for this batch and interleave. */
+int64_t mpcx_array_elems(int64_t batch, int64_t interleave, int64_t elems_per_instance);
+
+/* Creates a context on HIP device `device_id` (its own stream, staging buffers grown on demand). */
+int mpcx_create(mpcx_ctx **out, int device_id);
+void mpcx_destroy(mpcx_ctx *ctx);
+const char *mpcx_last_error(const mpcx_ctx *ctx);
+
+/*
+ * Condensed QP construction, batched.  Replaces Controller::form_lifted_matrices up to the Hessian
+ * (controller.rs:16-93) and the `O x - ref` / `M^T W4` pieces of compute_control_input and of the gain
+ * (controller.rs:125-127, :96), for `batch` independent plants:
+ *     Phi   (f r) x n        block i   = C A^(i+1)                                   [mat_o, controller.rs:32-44]
+ *     Gamma (f r) x (v m)    block i,k = C A^(i-k) B (k <= i); for rows i >= v the last block column holds
+ *                            C (sum_{s=0}^{i-v+1} A^s) B                              [mat_m, controller.rs:46-90]
+ *     H     (v m) x (v m)    = Gamma^T W4 Gamma + W3                                 [controller.rs:92-93]
+ *     fvec  (v m)            = Gamma^T W4 (Phi x0 - ref)
+ * Inputs per instance: A, B, C, x0 (n), ref (f r).  Shared: W3 (v m x v m dense), W4 (r x r block or dense
+ * (f r) x (f r), per dims->weights_mode).  Any output pointer may be NULL: that output is neither computed
+ * for its own sake nor stored.  x0 / ref may be NULL when fvec is NULL; W3 / W4 when H and fvec are NULL.
+ */
+int mpcx_qp_build_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, const double *B, const double *C,
+                      const double *W3, const double *W4, const double *x0, const double *ref, double *Phi,
+                      double *Gamma, double *H, double *fvec);
+int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, const double *B, const double *C,
+                          const double *W3, const double *W4, const double *x0, const double *ref, double *Phi,
+                          double *Gamma, double *H, double *fvec, void *stream);
+
+/*
+ * Open-loop rollout, batched.  Replaces simulator::system_simulate (simulator.rs:5-35; `step` and
+ * `compute_system_response`, simulator.rs:37-63, are thin wrappers over it) and, with T = 1,
+ * Controller::propagate_dynamics (controller.rs:101-115):
+ *     X n x (T+1): X[:,0] = x0, X[:,i+1] = A X[:,i] + B U[:,i];   Y r x T: Y[:,i] = C X[:,i].
+ * U is m x T (time along columns).  X or Y may be NULL.
+ */
+int mpcx_rollout_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, const double *B, const double *C,
+                     const double *x0, const double *U, double *X, double *Y);
+int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, const double *B, const double *C,
+                         const double *x0, const double *U, double *X, double *Y, void *stream);
+
+/*
+ * Reduces `count` f64 values at device pointer `buf` to one mpcx_stats record written to device memory
+ * `out_dev` (no counterpart in the reference: it is what sharded runs gather instead of the results).
+ */
+int mpcx_stats_f64_dev(mpcx_ctx *ctx, const double *buf, int64_t count, mpcx_stats *out_dev, void *stream);
+/* Same for a host-visible result: the record is copied to `out_host` and the call synchronises. */
+int mpcx_stats_f64(mpcx_ctx *ctx, const double *buf_dev, int64_t count, mpcx_stats *out_host);
+
+/*
+ * Re-arranges a batched array between two interleave widths on the device (src and dst must not overlap).
+ * No counterpart in the reference; callers holding one DMatrix per plant (W = 1) use it to reach the
+ * batch-interleaved layout and back.
+ */
+int mpcx_relayout_f64_dev(mpcx_ctx *ctx, int64_t batch, int64_t elems_per_instance, int64_t src_interleave,
+                          const double *src, int64_t dst_interleave, double *dst, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCX_H */

@@ -1,0 +1,343 @@
+// C ABI of libmpcx: argument checking, kernel-family dispatch, and the host-pointer convenience paths.
+// There is no CPU implementation behind these entry points.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "mpcx_internal.h"
+
+struct mpcx_ctx {
+    int device;
+    hipStream_t stream;
+    void *work;          // staging for host-pointer calls
+    size_t work_bytes;
+    void *stat_scratch;  // partial records of the stats reduction + one result record
+    char err[512];
+};
+
+namespace {
+
+using namespace mpcx;
+
+int fail(mpcx_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int hip_fail(mpcx_ctx *ctx, hipError_t e, const char *what) {
+    return fail(ctx, (int)e, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+int check_common(mpcx_ctx *ctx, const mpcx_dims *d, long long *W) {
+    if (!ctx) return MPCX_ERR_NULL;
+    if (!d) return fail(ctx, MPCX_ERR_NULL, "dims is NULL");
+    if (d->n < 1 || d->m < 1 || d->r < 1) return fail(ctx, MPCX_ERR_DIMS, "n, m, r must be >= 1 (got %d, %d, %d)", d->n, d->m, d->r);
+    if (d->batch < 0) return fail(ctx, MPCX_ERR_DIMS, "batch must be >= 0");
+    if (d->interleave < 0) return fail(ctx, MPCX_ERR_LAYOUT, "interleave must be >= 0");
+    long long w = d->interleave == 0 ? d->batch : d->interleave;
+    if (w < 1) w = 1;
+    if (w != 1 && w != d->batch && (w % 64) != 0)
+        return fail(ctx, MPCX_ERR_LAYOUT, "interleave %lld: must be 0 (= batch), 1, or a multiple of 64", (long long)d->interleave);
+    *W = w;
+    return MPCX_OK;
+}
+
+int ensure_work(mpcx_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->work_bytes) return MPCX_OK;
+    if (ctx->work) {
+        HIP_TRY(ctx, hipFree(ctx->work));
+        ctx->work = nullptr;
+        ctx->work_bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->work, bytes));
+    ctx->work_bytes = bytes;
+    return MPCX_OK;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct QpSizes {
+    long long A, B, C, x0, ref, W3, W4, Phi, Gamma, H, fvec;  // elements
+};
+
+QpSizes qp_sizes(const mpcx_dims *d) {
+    const long long n = d->n, m = d->m, r = d->r, f = d->f, v = d->v, bt = d->batch, il = d->interleave;
+    QpSizes s;
+    s.A = mpcx_array_elems(bt, il, n * n);
+    s.B = mpcx_array_elems(bt, il, n * m);
+    s.C = mpcx_array_elems(bt, il, r * n);
+    s.x0 = mpcx_array_elems(bt, il, n);
+    s.ref = mpcx_array_elems(bt, il, f * r);
+    s.W3 = v * m * v * m;
+    s.W4 = d->weights_mode == MPCX_WEIGHTS_DENSE ? f * r * f * r : r * r;
+    s.Phi = mpcx_array_elems(bt, il, f * r * n);
+    s.Gamma = mpcx_array_elems(bt, il, f * r * v * m);
+    s.H = mpcx_array_elems(bt, il, v * m * v * m);
+    s.fvec = mpcx_array_elems(bt, il, v * m);
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpcx_version(void) { return MPCX_VERSION; }
+
+int64_t mpcx_array_elems(int64_t batch, int64_t interleave, int64_t elems_per_instance) {
+    if (batch <= 0 || elems_per_instance <= 0) return 0;
+    const int64_t W = interleave == 0 ? batch : interleave;
+    if (W < 1) return 0;
+    const int64_t tiles = (batch + W - 1) / W;
+    return tiles * W * elems_per_instance;
+}
+
+int mpcx_create(mpcx_ctx **out, int device_id) {
+    if (!out) return MPCX_ERR_NULL;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return MPCX_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return MPCX_ERR_NO_DEVICE;
+    mpcx_ctx *ctx = new (std::nothrow) mpcx_ctx();
+    if (!ctx) return MPCX_ERR_NULL;
+    ctx->device = device_id;
+    ctx->work = nullptr;
+    ctx->work_bytes = 0;
+    ctx->stat_scratch = nullptr;
+    ctx->err[0] = 0;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return (int)e;
+    }
+    e = hipMalloc(&ctx->stat_scratch, stats_scratch_bytes() + 256);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return (int)e;
+    }
+    *out = ctx;
+    return MPCX_OK;
+}
+
+void mpcx_destroy(mpcx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->stat_scratch) (void)hipFree(ctx->stat_scratch);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mpcx_last_error(const mpcx_ctx *ctx) { return ctx ? ctx->err : "context is NULL"; }
+
+int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,
+                          const double *W3, const double *W4, const double *x0, const double *ref, double *Phi,
+                          double *Gamma, double *H, double *fvec, void *stream) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->f < 1 || d->v < 1 || d->v > d->f)
+        return fail(ctx, MPCX_ERR_DIMS, "need f >= 1 and 1 <= v <= f (got f=%d, v=%d)", d->f, d->v);
+    if (d->weights_mode != MPCX_WEIGHTS_BLOCK && d->weights_mode != MPCX_WEIGHTS_DENSE)
+        return fail(ctx, MPCX_ERR_DIMS, "unknown weights_mode %d", d->weights_mode);
+    if (d->batch == 0) return MPCX_OK;
+    if (!A || !B || !C) return fail(ctx, MPCX_ERR_NULL, "A, B and C are required");
+    if ((H || fvec) && !W4) return fail(ctx, MPCX_ERR_NULL, "W4 is required when H or fvec is requested");
+    if (H && !W3) return fail(ctx, MPCX_ERR_NULL, "W3 is required when H is requested");
+    if (fvec && (!x0 || !ref)) return fail(ctx, MPCX_ERR_NULL, "x0 and ref are required when fvec is requested");
+    if (!Phi && !Gamma && !H && !fvec) return MPCX_OK;
+
+    QpArgs a;
+    a.A = A; a.B = B; a.C = C; a.W3 = W3; a.W4 = W4; a.x0 = x0; a.ref = ref;
+    a.Phi = Phi; a.Gamma = Gamma; a.H = H; a.fvec = fvec;
+    a.batch = d->batch; a.W = W;
+    a.n = d->n; a.m = d->m; a.r = d->r; a.f = d->f; a.v = d->v;
+    a.weights_mode = d->weights_mode;
+    hipStream_t s = (hipStream_t)stream;
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = launch_qp_lane(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED) rc = launch_qp_wg(a, d->hessian_algo, s);
+    if (rc == MPCX_ERR_LAYOUT)
+        return fail(ctx, rc, "n=%d m=%d r=%d needs the workgroup kernels, which take instance-major data (interleave = 1)",
+                    d->n, d->m, d->r);
+    if (rc == MPCX_ERR_UNSUPPORTED)
+        return fail(ctx, rc, "n=%d m=%d r=%d f=%d v=%d weights_mode=%d does not fit the on-chip working set of any kernel",
+                    d->n, d->m, d->r, d->f, d->v, d->weights_mode);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "qp_build launch");
+    return MPCX_OK;
+}
+
+int mpcx_qp_build_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,
+                      const double *W3, const double *W4, const double *x0, const double *ref, double *Phi,
+                      double *Gamma, double *H, double *fvec) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->f < 1 || d->v < 1 || d->v > d->f)
+        return fail(ctx, MPCX_ERR_DIMS, "need f >= 1 and 1 <= v <= f (got f=%d, v=%d)", d->f, d->v);
+    if (d->batch == 0) return MPCX_OK;
+    if (!A || !B || !C) return fail(ctx, MPCX_ERR_NULL, "A, B and C are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const QpSizes z = qp_sizes(d);
+    const double *hin[7] = {A, B, C, W3, W4, x0, ref};
+    const long long nin[7] = {z.A, z.B, z.C, z.W3, z.W4, z.x0, z.ref};
+    double *hout[4] = {Phi, Gamma, H, fvec};
+    const long long nout[4] = {z.Phi, z.Gamma, z.H, z.fvec};
+    size_t off_in[7], off_out[4], total = 0;
+    for (int i = 0; i < 7; ++i) {
+        off_in[i] = total;
+        if (hin[i]) total += align256((size_t)nin[i] * sizeof(double));
+    }
+    for (int i = 0; i < 4; ++i) {
+        off_out[i] = total;
+        if (hout[i]) total += align256((size_t)nout[i] * sizeof(double));
+    }
+    rc = ensure_work(ctx, total);
+    if (rc != MPCX_OK) return rc;
+    char *base = (char *)ctx->work;
+    const double *din[7];
+    double *dout[4];
+    for (int i = 0; i < 7; ++i) {
+        din[i] = hin[i] ? (const double *)(base + off_in[i]) : nullptr;
+        if (hin[i])
+            HIP_TRY(ctx, hipMemcpyAsync((void *)din[i], hin[i], (size_t)nin[i] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (int i = 0; i < 4; ++i) dout[i] = hout[i] ? (double *)(base + off_out[i]) : nullptr;
+    rc = mpcx_qp_build_f64_dev(ctx, d, din[0], din[1], din[2], din[3], din[4], din[5], din[6], dout[0], dout[1], dout[2],
+                               dout[3], (void *)ctx->stream);
+    if (rc != MPCX_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (hout[i])
+            HIP_TRY(ctx, hipMemcpyAsync(hout[i], dout[i], (size_t)nout[i] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCX_OK;
+}
+
+int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,
+                         const double *x0, const double *U, double *X, double *Y, void *stream) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->T < 0) return fail(ctx, MPCX_ERR_DIMS, "T must be >= 0");
+    if (d->batch == 0) return MPCX_OK;
+    if (!A || !B || !C || !x0) return fail(ctx, MPCX_ERR_NULL, "A, B, C and x0 are required");
+    if (d->T > 0 && !U) return fail(ctx, MPCX_ERR_NULL, "U is required when T > 0");
+    if (!X && !Y) return MPCX_OK;
+    RolloutArgs a;
+    a.A = A; a.B = B; a.C = C; a.x0 = x0; a.U = U; a.X = X; a.Y = Y;
+    a.batch = d->batch; a.W = W; a.T = d->T;
+    a.n = d->n; a.m = d->m; a.r = d->r; a.u_shared = d->u_shared;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = (W == 1) ? MPCX_ERR_UNSUPPORTED : launch_rollout_lane(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED) rc = launch_rollout_group(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED && W == 1) rc = launch_rollout_lane(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED)
+        return fail(ctx, rc, "n=%d m=%d r=%d exceeds the rollout kernels' limit of 64 rows", d->n, d->m, d->r);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "rollout launch");
+    return MPCX_OK;
+}
+
+int mpcx_rollout_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,
+                     const double *x0, const double *U, double *X, double *Y) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->T < 0) return fail(ctx, MPCX_ERR_DIMS, "T must be >= 0");
+    if (d->batch == 0) return MPCX_OK;
+    if (!A || !B || !C || !x0) return fail(ctx, MPCX_ERR_NULL, "A, B, C and x0 are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long n = d->n, m = d->m, r = d->r, bt = d->batch, il = d->interleave, T = d->T;
+    const double *hin[5] = {A, B, C, x0, U};
+    const long long nin[5] = {mpcx_array_elems(bt, il, n * n), mpcx_array_elems(bt, il, n * m), mpcx_array_elems(bt, il, r * n),
+                              mpcx_array_elems(bt, il, n), d->u_shared ? m * T : mpcx_array_elems(bt, il, m * T)};
+    double *hout[2] = {X, Y};
+    const long long nout[2] = {mpcx_array_elems(bt, il, n * (T + 1)), mpcx_array_elems(bt, il, r * T)};
+    size_t off_in[5], off_out[2], total = 0;
+    for (int i = 0; i < 5; ++i) {
+        off_in[i] = total;
+        if (hin[i]) total += align256((size_t)nin[i] * sizeof(double));
+    }
+    for (int i = 0; i < 2; ++i) {
+        off_out[i] = total;
+        if (hout[i]) total += align256((size_t)nout[i] * sizeof(double));
+    }
+    rc = ensure_work(ctx, total ? total : 256);
+    if (rc != MPCX_OK) return rc;
+    char *base = (char *)ctx->work;
+    const double *din[5];
+    double *dout[2];
+    for (int i = 0; i < 5; ++i) {
+        din[i] = hin[i] ? (const double *)(base + off_in[i]) : nullptr;
+        if (hin[i] && nin[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync((void *)din[i], hin[i], (size_t)nin[i] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (int i = 0; i < 2; ++i) dout[i] = hout[i] ? (double *)(base + off_out[i]) : nullptr;
+    rc = mpcx_rollout_f64_dev(ctx, d, din[0], din[1], din[2], din[3], din[4], dout[0], dout[1], (void *)ctx->stream);
+    if (rc != MPCX_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (hout[i] && nout[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(hout[i], dout[i], (size_t)nout[i] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCX_OK;
+}
+
+int mpcx_stats_f64_dev(mpcx_ctx *ctx, const double *buf, int64_t count, mpcx_stats *out_dev, void *stream) {
+    if (!ctx) return MPCX_ERR_NULL;
+    if (!out_dev || (count > 0 && !buf)) return fail(ctx, MPCX_ERR_NULL, "buf / out_dev is NULL");
+    if (count < 0) return fail(ctx, MPCX_ERR_DIMS, "count must be >= 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = launch_stats(buf, count, out_dev, ctx->stat_scratch, stats_scratch_bytes(), (hipStream_t)stream);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "stats launch");
+    return MPCX_OK;
+}
+
+int mpcx_stats_f64(mpcx_ctx *ctx, const double *buf_dev, int64_t count, mpcx_stats *out_host) {
+    if (!ctx) return MPCX_ERR_NULL;
+    if (!out_host) return fail(ctx, MPCX_ERR_NULL, "out_host is NULL");
+    mpcx_stats *rec = (mpcx_stats *)((char *)ctx->stat_scratch + stats_scratch_bytes());
+    int rc = mpcx_stats_f64_dev(ctx, buf_dev, count, rec, (void *)ctx->stream);
+    if (rc != MPCX_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, rec, sizeof(mpcx_stats), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCX_OK;
+}
+
+int mpcx_relayout_f64_dev(mpcx_ctx *ctx, int64_t batch, int64_t elems_per_instance, int64_t src_interleave,
+                          const double *src, int64_t dst_interleave, double *dst, void *stream) {
+    if (!ctx) return MPCX_ERR_NULL;
+    if (batch < 0 || elems_per_instance < 0) return fail(ctx, MPCX_ERR_DIMS, "batch and elems_per_instance must be >= 0");
+    if (batch == 0 || elems_per_instance == 0) return MPCX_OK;
+    if (!src || !dst) return fail(ctx, MPCX_ERR_NULL, "src / dst is NULL");
+    const long long Ws = src_interleave == 0 ? batch : src_interleave, Wd = dst_interleave == 0 ? batch : dst_interleave;
+    if (Ws < 1 || Wd < 1) return fail(ctx, MPCX_ERR_LAYOUT, "interleave must be >= 0");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = launch_relayout(batch, elems_per_instance, Ws, src, Wd, dst, (hipStream_t)stream);
+    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "relayout: array too large for one launch");
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "relayout launch");
+    return MPCX_OK;
+}
+
+}  // extern "C"

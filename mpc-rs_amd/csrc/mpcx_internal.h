@@ -1,0 +1,47 @@
+// Internal declarations shared by the kernel files and the C ABI of libmpcx (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpcx.h"
+
+namespace mpcx {
+
+// Arguments of one batched QP build; every pointer is a device pointer, W is the resolved interleave width
+// (1 <= W <= batch).
+struct QpArgs {
+    const double *A, *B, *C, *W3, *W4, *x0, *ref;
+    double *Phi, *Gamma, *H, *fvec;
+    long long batch, W;
+    int n, m, r, f, v;
+    int weights_mode;
+};
+
+struct RolloutArgs {
+    const double *A, *B, *C, *x0, *U;
+    double *X, *Y;
+    long long batch, W, T;
+    int n, m, r;
+    int u_shared;
+};
+
+// Each launcher returns hipSuccess / a hipError_t, or MPCX_ERR_UNSUPPORTED when the dimensions are outside
+// what that kernel family holds on chip (the caller then tries the next family).
+int launch_qp_lane(const QpArgs &a, hipStream_t s);
+int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s);
+int launch_rollout_lane(const RolloutArgs &a, hipStream_t s);
+int launch_rollout_group(const RolloutArgs &a, hipStream_t s);
+int launch_stats(const double *buf, long long count, mpcx_stats *out_dev, void *scratch, size_t scratch_bytes,
+                 hipStream_t s);
+size_t stats_scratch_bytes();
+int launch_relayout(long long batch, long long E, long long Wsrc, const double *src, long long Wdst, double *dst,
+                    hipStream_t s);
+
+// Index of element e of instance b in an array with E elements per instance and interleave width W.
+__host__ __device__ inline long long elem_index(long long b, long long e, long long E, long long W) {
+    const long long tile = b / W;
+    return tile * E * W + e * W + (b - tile * W);
+}
+
+}  // namespace mpcx

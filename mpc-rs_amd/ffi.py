@@ -1,0 +1,212 @@
+"""ctypes binding of libmpcx.so, the C ABI declared in include/mpcx.h.
+
+The library is the hand-written HIP (gfx950) implementation; there is no other compute path.  Loading fails
+with an explicit error when the shared object is missing, and every call raises :class:`MpcxError` on a
+non-zero status (the message comes from ``mpcx_last_error``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import layout as L
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmpcx.so")
+
+OK = 0
+ERR_NULL, ERR_DIMS, ERR_LAYOUT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SINGULAR = -1, -2, -3, -4, -5, -6
+WEIGHTS_BLOCK, WEIGHTS_DENSE = 0, 1
+HESSIAN_AUTO, HESSIAN_CONTRACT, HESSIAN_STRUCTURED = 0, 1, 2
+
+# every symbol include/mpcx.h declares
+EXPORTS = (
+    "mpcx_version", "mpcx_array_elems", "mpcx_create", "mpcx_destroy", "mpcx_last_error",
+    "mpcx_qp_build_f64", "mpcx_qp_build_f64_dev", "mpcx_rollout_f64", "mpcx_rollout_f64_dev",
+    "mpcx_stats_f64_dev", "mpcx_stats_f64", "mpcx_relayout_f64_dev",
+)
+
+
+class MpcxError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mpcx error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class Dims(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("r", C.c_int32), ("f", C.c_int32), ("v", C.c_int32),
+        ("weights_mode", C.c_int32), ("hessian_algo", C.c_int32), ("u_shared", C.c_int32),
+        ("batch", C.c_int64), ("T", C.c_int64), ("interleave", C.c_int64),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("count", C.c_int64), ("non_finite", C.c_int64), ("sum", C.c_double), ("sum_sq", C.c_double),
+        ("max_abs", C.c_double), ("checksum", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C mpc-rs_amd/csrc` (or __graft_entry__.build()). "
+            "There is no fallback compute path.")
+    lb = C.CDLL(LIB_PATH)
+    vp, dp, i64 = C.c_void_p, C.c_void_p, C.c_int64
+    lb.mpcx_version.restype = C.c_int
+    lb.mpcx_array_elems.argtypes = [i64, i64, i64]
+    lb.mpcx_array_elems.restype = i64
+    lb.mpcx_create.argtypes = [C.POINTER(vp), C.c_int]
+    lb.mpcx_create.restype = C.c_int
+    lb.mpcx_destroy.argtypes = [vp]
+    lb.mpcx_destroy.restype = None
+    lb.mpcx_last_error.argtypes = [vp]
+    lb.mpcx_last_error.restype = C.c_char_p
+    lb.mpcx_qp_build_f64.argtypes = [vp, C.POINTER(Dims)] + [dp] * 11
+    lb.mpcx_qp_build_f64.restype = C.c_int
+    lb.mpcx_qp_build_f64_dev.argtypes = [vp, C.POINTER(Dims)] + [dp] * 11 + [vp]
+    lb.mpcx_qp_build_f64_dev.restype = C.c_int
+    lb.mpcx_rollout_f64.argtypes = [vp, C.POINTER(Dims)] + [dp] * 7
+    lb.mpcx_rollout_f64.restype = C.c_int
+    lb.mpcx_rollout_f64_dev.argtypes = [vp, C.POINTER(Dims)] + [dp] * 7 + [vp]
+    lb.mpcx_rollout_f64_dev.restype = C.c_int
+    lb.mpcx_stats_f64_dev.argtypes = [vp, dp, i64, vp, vp]
+    lb.mpcx_stats_f64_dev.restype = C.c_int
+    lb.mpcx_stats_f64.argtypes = [vp, dp, i64, C.POINTER(Stats)]
+    lb.mpcx_stats_f64.restype = C.c_int
+    lb.mpcx_relayout_f64_dev.argtypes = [vp, i64, i64, i64, dp, i64, dp, vp]
+    lb.mpcx_relayout_f64_dev.restype = C.c_int
+    _lib = lb
+    return lb
+
+
+def _hp(a):
+    """Host pointer of a contiguous float64 numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_dims(n, m, r, f=1, v=1, batch=1, T=0, interleave=L.INTERLEAVE_AOS, weights_mode=WEIGHTS_BLOCK,
+              hessian_algo=HESSIAN_AUTO, u_shared=0) -> Dims:
+    return Dims(n=n, m=m, r=r, f=f, v=v, weights_mode=weights_mode, hessian_algo=hessian_algo, u_shared=u_shared,
+                batch=batch, T=T, interleave=interleave)
+
+
+class Context:
+    """One mpcx_ctx: bound to one device; not thread-safe."""
+
+    def __init__(self, device: int = 0):
+        self._lib = lib()
+        h = C.c_void_p()
+        rc = self._lib.mpcx_create(C.byref(h), device)
+        if rc != OK:
+            raise MpcxError(rc, "mpcx_create failed (no usable HIP device?)" if rc == ERR_NO_DEVICE else "mpcx_create failed")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mpcx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise MpcxError(rc, self._lib.mpcx_last_error(self._h).decode())
+
+    # ---- raw calls: pointers are ints / c_void_p (device) or numpy arrays (host) ----
+    def qp_build_dev(self, dims: Dims, A, B, Cm, W3, W4, x0, ref, Phi, Gamma, H, fvec, stream=0):
+        self._check(self._lib.mpcx_qp_build_f64_dev(self._h, C.byref(dims), A, B, Cm, W3, W4, x0, ref, Phi, Gamma, H,
+                                                    fvec, stream))
+
+    def rollout_dev(self, dims: Dims, A, B, Cm, x0, U, X, Y, stream=0):
+        self._check(self._lib.mpcx_rollout_f64_dev(self._h, C.byref(dims), A, B, Cm, x0, U, X, Y, stream))
+
+    def stats_dev(self, buf, count: int, out_dev, stream=0):
+        self._check(self._lib.mpcx_stats_f64_dev(self._h, buf, count, out_dev, stream))
+
+    def stats(self, buf_dev, count: int) -> dict:
+        st = Stats()
+        self._check(self._lib.mpcx_stats_f64(self._h, buf_dev, count, C.byref(st)))
+        return st.as_dict()
+
+    def relayout_dev(self, batch, elems, src_il, src, dst_il, dst, stream=0):
+        self._check(self._lib.mpcx_relayout_f64_dev(self._h, batch, elems, src_il, src, dst_il, dst, stream))
+
+    # ---- host-array convenience: (batch, rows, cols) numpy in, numpy out, through the host-pointer ABI ----
+    def qp_build(self, A, B, Cm, f, v, W3=None, W4=None, x0=None, ref=None, interleave=L.INTERLEAVE_AOS,
+                 weights_mode=WEIGHTS_BLOCK, hessian_algo=HESSIAN_AUTO, want=("Phi", "Gamma", "H", "fvec")):
+        A = np.asarray(A, dtype=np.float64)
+        B = np.asarray(B, dtype=np.float64)
+        Cm = np.asarray(Cm, dtype=np.float64)
+        batch, n = A.shape[0], A.shape[1]
+        m, r = B.shape[2], Cm.shape[1]
+        d = make_dims(n, m, r, f, v, batch, 0, interleave, weights_mode, hessian_algo)
+        shapes = {"Phi": (f * r, n), "Gamma": (f * r, v * m), "H": (v * m, v * m), "fvec": (v * m, 1)}
+        ins = [L.pack(A, interleave), L.pack(B, interleave), L.pack(Cm, interleave),
+               None if W3 is None else L.colmajor(W3), None if W4 is None else L.colmajor(W4),
+               None if x0 is None else L.pack(np.asarray(x0, dtype=np.float64).reshape(batch, n, 1), interleave),
+               None if ref is None else L.pack(np.asarray(ref, dtype=np.float64).reshape(batch, f * r, 1), interleave)]
+        outs = {}
+        for k, (rows, cols) in shapes.items():
+            outs[k] = np.full(max(L.array_elems(batch, interleave, rows * cols), 1), np.nan) if k in want else None
+        self._check(self._lib.mpcx_qp_build_f64(self._h, C.byref(d), *[_hp(x) for x in ins],
+                                                *[_hp(outs[k]) for k in ("Phi", "Gamma", "H", "fvec")]))
+        res = {}
+        for k, (rows, cols) in shapes.items():
+            if outs[k] is not None:
+                res[k] = L.unpack(outs[k], batch, rows, cols, interleave)
+        return res
+
+    def rollout(self, A, B, Cm, x0, U, interleave=L.INTERLEAVE_AOS, want=("X", "Y")):
+        """U is (batch, m, T) or, shared by all instances, (m, T).  Returns X (batch, n, T+1), Y (batch, r, T)."""
+        A = np.asarray(A, dtype=np.float64)
+        B = np.asarray(B, dtype=np.float64)
+        Cm = np.asarray(Cm, dtype=np.float64)
+        U = np.asarray(U, dtype=np.float64)
+        batch, n = A.shape[0], A.shape[1]
+        m, r = B.shape[2], Cm.shape[1]
+        shared = U.ndim == 2
+        T = U.shape[-1]
+        d = make_dims(n, m, r, 1, 1, batch, T, interleave, u_shared=int(shared))
+        u_buf = L.colmajor(U) if shared else L.pack(U, interleave)
+        if u_buf.size == 0:
+            u_buf = np.zeros(1)
+        ins = [L.pack(A, interleave), L.pack(B, interleave), L.pack(Cm, interleave),
+               L.pack(np.asarray(x0, dtype=np.float64).reshape(batch, n, 1), interleave), u_buf]
+        X = np.full(max(L.array_elems(batch, interleave, n * (T + 1)), 1), np.nan) if "X" in want else None
+        Y = np.full(max(L.array_elems(batch, interleave, r * T), 1), np.nan) if "Y" in want else None
+        self._check(self._lib.mpcx_rollout_f64(self._h, C.byref(d), *[_hp(x) for x in ins], _hp(X), _hp(Y)))
+        res = {}
+        if X is not None:
+            res["X"] = L.unpack(X, batch, n, T + 1, interleave)
+        if Y is not None:
+            res["Y"] = L.unpack(Y, batch, r, T, interleave)
+        return res

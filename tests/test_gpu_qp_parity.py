@@ -1,0 +1,111 @@
+"""GPU parity of the condensed-QP build (Phi, Gamma, H, fvec) against the C oracle, through the C ABI.
+
+Tolerance: relative Frobenius error <= 1e-10 per output, over the batch and for the worst single instance
+(tests/helpers.py RTOL).  The GPU evaluates the same quantities with a different association (Markov recurrence
+instead of re-multiplied powers, running sums along block diagonals of H), so equality is not bitwise.
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_close, oracle_qp, random_stable_plants
+from mpc_rs_amd import ffi, synth
+from oracle import oracle_ffi as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, data, interleave, want=("Phi", "Gamma", "H", "fvec"), **kw):
+    return ctx.qp_build(data["A"], data["B"], data["C"], data["f"], data["v"], W3=data["W3"], W4=data["Q"],
+                        x0=data["x0"], ref=data["ref"], interleave=interleave, want=want, **kw)
+
+
+@pytest.mark.parametrize("name,batch", [("msd", 1000), ("two_mass", 777)])
+@pytest.mark.parametrize("interleave", [0, 64, 256, 1])
+def test_lane_kernel_workloads(ctx, name, batch, interleave):
+    data = synth.make_batch(name, batch)
+    want = oracle_qp(orc, data)
+    got = _run(ctx, data, interleave)
+    for k in ("Phi", "Gamma", "H", "fvec"):
+        assert_close(got[k], want[k], f"{name} W={interleave} {k}")
+
+
+@pytest.mark.parametrize("n,m,r", [(1, 1, 1), (3, 1, 1), (5, 1, 1), (6, 1, 1), (2, 2, 2), (4, 2, 2), (6, 2, 2),
+                                   (3, 2, 1), (4, 2, 1), (3, 1, 2), (4, 1, 2)])
+@pytest.mark.parametrize("f,v", [(8, 8), (6, 3), (9, 1), (7, 2), (1, 1)])
+def test_lane_kernel_shapes_and_held_input(ctx, n, m, r, f, v):
+    rng = np.random.default_rng(1000 * n + 100 * m + 10 * r + f + v)
+    batch = 130
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    w3 = rng.standard_normal((v * m, v * m))
+    q = rng.standard_normal((r, r))  # not symmetric on purpose: the kernels may not assume symmetry
+    data = dict(A=A, B=B, C=C, W3=w3, Q=q, x0=rng.standard_normal((batch, n)), ref=rng.standard_normal((batch, f * r)),
+                f=f, v=v)
+    want = oracle_qp(orc, data)
+    for il in (0, 1):
+        got = _run(ctx, data, il)
+        for k in ("Phi", "Gamma", "H", "fvec"):
+            assert_close(got[k], want[k], f"n{n} m{m} r{r} f{f} v{v} W={il} {k}")
+
+
+@pytest.mark.parametrize("n,m,r,f,v", [(12, 4, 12, 10, 10), (12, 4, 12, 9, 4), (8, 2, 2, 40, 40), (8, 2, 2, 30, 7),
+                                       (7, 3, 5, 6, 6), (9, 1, 1, 12, 2), (16, 5, 3, 5, 1), (10, 2, 4, 3, 3)])
+def test_workgroup_kernel_shapes(ctx, n, m, r, f, v):
+    rng = np.random.default_rng(n * 7 + m * 5 + r * 3 + f + v)
+    batch = 9
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    data = dict(A=A, B=B, C=C, W3=rng.standard_normal((v * m, v * m)), Q=rng.standard_normal((r, r)),
+                x0=rng.standard_normal((batch, n)), ref=rng.standard_normal((batch, f * r)), f=f, v=v)
+    want = oracle_qp(orc, data)
+    got = _run(ctx, data, 1)
+    for k in ("Phi", "Gamma", "H", "fvec"):
+        assert_close(got[k], want[k], f"wg n{n} m{m} r{r} f{f} v{v} {k}")
+
+
+def test_quadrotor_and_long_horizon_workloads(ctx):
+    for name, batch in (("quadrotor", 6), ("long", 2)):
+        data = synth.make_batch(name, batch)
+        want = oracle_qp(orc, data)
+        got = _run(ctx, data, 1)
+        for k in ("Phi", "Gamma", "H", "fvec"):
+            assert_close(got[k], want[k], f"{name} {k}")
+
+
+def test_output_subsets(ctx):
+    for name, il in (("two_mass", 0), ("quadrotor", 1)):
+        data = synth.make_batch(name, 70 if name == "two_mass" else 3)
+        full = _run(ctx, data, il)
+        for subset in (("Phi",), ("Gamma",), ("H",), ("fvec",), ("Phi", "H"), ("Gamma", "fvec")):
+            part = _run(ctx, data, il, want=subset)
+            assert set(part) == set(subset)
+            for k in subset:
+                assert np.array_equal(part[k], full[k]), f"{name}: {k} differs when only {subset} is requested"
+
+
+def test_batch_of_one_and_empty(ctx):
+    data = synth.make_batch("two_mass", 1)
+    want = oracle_qp(orc, data)
+    for il in (0, 1):
+        got = _run(ctx, data, il)
+        for k in got:
+            assert_close(got[k], want[k], f"batch 1 W={il} {k}")
+    empty = synth.make_batch("two_mass", 0)
+    got = _run(ctx, empty, 1)
+    assert got["Phi"].shape == (0, 20, 4) and got["H"].shape == (0, 20, 20)
+
+
+def test_argument_errors(ctx):
+    data = synth.make_batch("two_mass", 4)
+    with pytest.raises(ffi.MpcxError) as e:
+        ctx.qp_build(data["A"], data["B"], data["C"], 5, 6, W3=np.zeros((6, 6)), W4=data["Q"], x0=data["x0"],
+                     ref=np.zeros((4, 5)))
+    assert e.value.code == ffi.ERR_DIMS
+    with pytest.raises(ffi.MpcxError) as e:
+        ctx.qp_build(data["A"], data["B"], data["C"], 20, 20, W3=None, W4=data["Q"], x0=data["x0"], ref=data["ref"])
+    assert e.value.code == ffi.ERR_NULL
+    with pytest.raises(ffi.MpcxError) as e:
+        _run(ctx, data, 48)  # not 0, 1 or a multiple of 64
+    assert e.value.code == ffi.ERR_LAYOUT
+    big = synth.make_batch("quadrotor", 2)
+    with pytest.raises(ffi.MpcxError) as e:
+        _run(ctx, big, 0)  # workgroup kernels take instance-major data only
+    assert e.value.code == ffi.ERR_LAYOUT

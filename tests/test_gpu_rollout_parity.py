@@ -1,0 +1,69 @@
+"""GPU parity of the batched rollout (simulator.rs system_simulate / controller.rs propagate_dynamics) against the
+C oracle, plus the consistency property that ties the rollout to the QP build:
+    Phi x0 + Gamma u_seq == [y_1 ... y_f]   when u is held at u_(v-1) past the control horizon.
+Tolerance: relative Frobenius error <= 1e-10 (tests/helpers.py RTOL).
+"""
+import numpy as np
+import pytest
+
+from helpers import assert_close, random_stable_plants
+from mpc_rs_amd import synth
+from oracle import oracle_ffi as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,batch", [("msd", 300), ("two_mass", 129)])
+@pytest.mark.parametrize("interleave", [0, 64, 1])
+def test_rollout_step_response(ctx, name, batch, interleave):
+    d = synth.make_batch(name, batch)
+    X, Y, _ = orc.rollout_batch(d["A"], d["B"], d["C"], np.zeros((batch, d["n"])), d["U"], threads=4)
+    got = ctx.rollout(d["A"], d["B"], d["C"], np.zeros((batch, d["n"])), d["U"], interleave=interleave)
+    assert_close(got["X"], X, f"{name} W={interleave} X")
+    assert_close(got["Y"], Y, f"{name} W={interleave} Y")
+
+
+@pytest.mark.parametrize("n,m,r,T", [(2, 1, 1, 50), (4, 2, 2, 33), (3, 2, 1, 7), (12, 4, 12, 60), (8, 2, 2, 90),
+                                     (17, 3, 5, 20), (64, 64, 64, 3), (5, 1, 1, 1), (6, 2, 2, 0)])
+@pytest.mark.parametrize("interleave", [0, 1])
+def test_rollout_shapes_per_instance_inputs(ctx, n, m, r, T, interleave):
+    rng = np.random.default_rng(n * 31 + m * 7 + r + T)
+    batch = 70
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    x0 = rng.standard_normal((batch, n))
+    U = rng.standard_normal((batch, m, T))
+    X, Y, _ = orc.rollout_batch(A, B, C, x0, U, threads=4)
+    got = ctx.rollout(A, B, C, x0, U, interleave=interleave)
+    assert got["X"].shape == (batch, n, T + 1) and got["Y"].shape == (batch, r, T)
+    if T == 0:
+        assert np.all(got["X"] == 0.0)  # simulator.rs:13-17: x0 is only copied inside the loop
+        return
+    assert_close(got["X"], X, f"n{n} m{m} r{r} T{T} W={interleave} X")
+    assert_close(got["Y"], Y, f"n{n} m{m} r{r} T{T} W={interleave} Y")
+
+
+def test_propagate_dynamics_is_rollout_with_T1(ctx):
+    rng = np.random.default_rng(5)
+    A, B, C = random_stable_plants(rng, 40, 4, 1, 1)
+    x = rng.standard_normal((40, 4))
+    u = rng.standard_normal((40, 1, 1))
+    got = ctx.rollout(A, B, C, x, u, interleave=0)
+    for b in range(40):
+        xn, y = orc.propagate_dynamics(A[b], B[b], C[b], u[b, :, 0], x[b])
+        assert_close(got["X"][b:b + 1, :, 1], xn[None], "x_next")
+        assert_close(got["Y"][b:b + 1, :, 0], y[None], "y")
+
+
+@pytest.mark.parametrize("name,batch,il,f,v", [("two_mass", 500, 0, 20, 20), ("two_mass", 200, 0, 20, 6),
+                                               ("quadrotor", 4, 1, 12, 5), ("long", 3, 1, 60, 60)])
+def test_prediction_consistency(ctx, name, batch, il, f, v):
+    d = synth.make_batch(name, batch, f=f, v=v)
+    n, m, r = d["n"], d["m"], d["r"]
+    rng = np.random.default_rng(11)
+    useq = rng.standard_normal((batch, v, m))
+    U = np.concatenate([useq, np.repeat(useq[:, -1:, :], f - v + 1, axis=1)], axis=1).transpose(0, 2, 1)  # (batch, m, f+1)
+    qp = ctx.qp_build(d["A"], d["B"], d["C"], f, v, interleave=il, want=("Phi", "Gamma"))
+    ro = ctx.rollout(d["A"], d["B"], d["C"], d["x0"], np.ascontiguousarray(U), interleave=il)
+    pred = np.einsum("bij,bj->bi", qp["Phi"], d["x0"]) + np.einsum("bij,bj->bi", qp["Gamma"], useq.reshape(batch, v * m))
+    ys = ro["Y"][:, :, 1:f + 1].transpose(0, 2, 1).reshape(batch, f * r)  # y_1..y_f stacked
+    assert_close(pred, ys, f"{name} prediction consistency", tol=1e-9)
