@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched MPC hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload two_mass|msd|quadrotor|long]
+                    [--op qp|rollout] [--batch B_per_gpu] [--interleave W]
+
+One "step" = one pass of the hot path over the rank's resident shard of synthetic plants: for --op qp one call of
+mpcx_qp_build_f64_dev storing Phi, Gamma, H and fvec for every instance; for --op rollout one call of
+mpcx_rollout_f64_dev storing X and Y.  Inputs and outputs live in HBM before the timed region starts.  Instances
+are sharded by index across ranks (one process per GPU, no collective on the data path, "weak" scaling: the
+per-GPU batch is fixed); after the timed region the ranks all-gather one fixed-size statistics record each over
+RCCL.  Rank 0 prints ONE JSON line.
+
+The default workload is the one the headline metric is quoted on: the reference's two-mass plant (n=4, m=1, r=1,
+f=v=20) perturbed per instance, 1,048,576 instances per GPU (8,388,608 over 8 GPUs).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12      # B/s, MI355X HBM3E
+FP64_PEAK = 78.6e12    # FLOP/s, MI355X FP64 vector = matrix
+
+DEFAULT_BATCH = {"two_mass": 1 << 20, "msd": 65536, "quadrotor": 16384, "long": 1024}
+
+
+def bytes_qp(n, m, r, f, v):
+    return 8 * (n * n + n * m + r * n + n + f * r + f * r * n + f * r * v * m + (v * m) ** 2 + v * m)
+
+
+def bytes_rollout(n, m, r, T):
+    return 8 * (n * n + n * m + r * n + n + m * T + n * (T + 1) + r * T)
+
+
+def flops_h(m, r, f, v):
+    return (f * r) * (v * m) * (v * m + 1) + 2 * f * r * r * v * m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="two_mass", choices=sorted(DEFAULT_BATCH))
+    ap.add_argument("--op", default="qp", choices=["qp", "rollout"])
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's own)")
+    ap.add_argument("--interleave", type=int, default=-1, help="-1: layout the kernels are native in")
+    ap.add_argument("--hessian", type=int, default=0, help="0 auto, 1 dense contraction, 2 structured")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="instances timed on the CPU (default: ~15 s worth)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from mpc_rs_amd import ffi, layout as L, shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctx = ffi.Context(local_rank)
+
+    wl = synth.WORKLOADS[args.workload]
+    n, m, r, f, v, T = wl["n"], wl["m"], wl["r"], wl["f"], wl["v"], wl["T"]
+    per_gpu = args.batch or DEFAULT_BATCH[args.workload]
+    lane_native = (m <= 2 and r <= 2 and n <= 6)
+    il = args.interleave if args.interleave >= 0 else (L.INTERLEAVE_FULL if lane_native else L.INTERLEAVE_AOS)
+    start, count = shard.shard_range(per_gpu * world, world, rank)
+    assert count == per_gpu
+
+    # ---- synthetic shard, generated in chunks on the host and made resident in HBM ----
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    d = synth.make_batch(args.workload, count, start=start)
+    bufs = {k: to_dev(L.pack(d[k], il)) for k in ("A", "B", "C")}
+    bufs["x0"] = to_dev(L.pack(d["x0"].reshape(count, n, 1), il))
+    bufs["ref"] = to_dev(L.pack(d["ref"].reshape(count, f * r, 1), il))
+    bufs["W3"] = to_dev(L.colmajor(d["W3"]))
+    bufs["Q"] = to_dev(L.colmajor(d["Q"]))
+    bufs["U"] = to_dev(L.colmajor(d["U"]))
+
+    def out(elems):
+        return torch.empty(L.array_elems(count, il, elems), dtype=torch.float64, device=dev)
+
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+    if args.op == "qp":
+        outs = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
+        dims = ffi.make_dims(n, m, r, f, v, count, 0, il, ffi.WEIGHTS_BLOCK, args.hessian)
+
+        def step():
+            ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(),
+                             bufs["W3"].data_ptr(), bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(),
+                             outs["Phi"].data_ptr(), outs["Gamma"].data_ptr(), outs["H"].data_ptr(),
+                             outs["fvec"].data_ptr(), sp)
+        unit_bytes = bytes_qp(n, m, r, f, v)
+        metric, unit = "batched MPC QP builds/sec (Phi,Gamma,H,f)", "builds/s"
+        check_buf = outs["H"]
+    else:
+        outs = {"X": out(n * (T + 1)), "Y": out(r * T)}
+        dims = ffi.make_dims(n, m, r, 1, 1, count, T, il, u_shared=1)
+
+        def step():
+            ctx.rollout_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["x0"].data_ptr(),
+                            bufs["U"].data_ptr(), outs["X"].data_ptr(), outs["Y"].data_ptr(), sp)
+        unit_bytes = bytes_rollout(n, m, r, T) - 8 * m * T  # the shared input is read once, not per instance
+        metric, unit = "batched state-space rollout trajectories/sec (X,Y)", "trajectories/s"
+        check_buf = outs["X"]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
+
+    # ---- statistics record of this shard; ranks exchange records (RCCL), never results ----
+    rec = torch.zeros(6, dtype=torch.int64, device=dev)
+    ctx.stats_dev(check_buf.data_ptr(), check_buf.numel(), rec.data_ptr(), sp)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        recs = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(recs, rec)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    else:
+        recs = [rec]
+    torch.cuda.synchronize()
+    elapsed = float(tmax.item())
+    merged = shard.merge_stats([shard.stats_from_words(x.cpu().numpy()) for x in recs])
+
+    if rank == 0:
+        total = per_gpu * world
+        value = total * args.steps / elapsed
+        achieved = unit_bytes * per_gpu / (kernel_ms * 1e-3)
+        res = {
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: n={n} m={m} r={r} f=v={f}" + (f" T={T}" if args.op == "rollout" else ""),
+                       "op": args.op, "batch_per_gpu": per_gpu, "global_batch": total, "interleave": il,
+                       "parallelism": f"batch-sharded x{world}", "hessian_algo": args.hessian},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": _traffic(args, per_gpu),
+                         "kernel_ms": kernel_ms, "bytes_per_unit": unit_bytes},
+            "check": {"elements": merged["count"], "non_finite": merged["non_finite"], "sum_sq": merged["sum_sq"],
+                      "checksum": "%016x" % merged["checksum"]},
+        }
+        if args.op == "qp":
+            res["roofline"]["flops_H_per_unit"] = flops_h(m, r, f, v)
+            res["roofline"]["fp64_frac_of_H_flops"] = flops_h(m, r, f, v) * per_gpu / (kernel_ms * 1e-3) / FP64_PEAK
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = _cpu_baseline(args, d, n, m, r, f, v, T, unit)
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _traffic(args, per_gpu):
+    """HBM bytes per launch from the PMC passes recorded under profiles/ (null when no matching record)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+        rec = table.get(f"{args.op}:{args.workload}:{per_gpu}")
+        return rec["hbm_bytes_per_launch"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _cpu_baseline(args, d, n, m, r, f, v, T, unit):
+    """The CPU oracle (a port that keeps the reference's algorithmic structure) on a bounded sample of the same
+    workload, all host cores of this box's share, timed around the C call only."""
+    from mpc_rs_amd import synth
+    from oracle import oracle_ffi as orc
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    est = {"two_mass": 1.2e4, "msd": 1.5e4, "quadrotor": 8.0, "long": 0.4}[args.workload] * cores  # builds/s, rough
+    if args.op == "rollout":
+        est = 2.0e4 * cores * (200.0 / max(T, 1))
+    sample = args.cpu_sample or int(max(cores, min(d["A"].shape[0], est * 12.0)))
+    sl = slice(0, sample)
+    tm = {}
+    if args.op == "qp":
+        w4 = synth.dense_w4(d["Q"], f)
+        orc.qp_build_batch(d["A"][sl], d["B"][sl], d["C"][sl], d["W3"], w4, d["x0"][sl], d["ref"][sl], f, v,
+                           threads=cores, timing=tm)
+        secs = tm["seconds"]
+    else:
+        orc.rollout_batch(d["A"][sl], d["B"][sl], d["C"][sl], d["x0"][sl], d["U"], threads=cores, timing=tm)
+        secs = tm["seconds"]
+    return {"value": sample / secs, "unit": unit, "cores": cores, "kind": "port",
+            "sample": f"first {sample} instances of the same workload, {secs:.1f} s, OpenMP over instances"}
+
+
+if __name__ == "__main__":
+    main()

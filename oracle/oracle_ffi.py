@@ -175,11 +175,14 @@ def try_inverse(a, variant=""):
     return bool(ok), _from_cm(flat, n, n)
 
 
-def qp_build_batch(A, B, Cm, W3, W4, x0, ref, f, v, threads=1, variant="", want=("Phi", "Gamma", "H", "fvec")):
+def qp_build_batch(A, B, Cm, W3, W4, x0, ref, f, v, threads=1, variant="", want=("Phi", "Gamma", "H", "fvec"),
+                   timing=None):
     """Instance-major batch: A (batch, n, n) etc. as (row, col) arrays per instance; W3/W4 shared.
 
-    Returns dict of (batch, rows, cols) arrays and the thread count used.
+    Returns dict of (batch, rows, cols) arrays and the thread count used.  When `timing` is a dict, the wall
+    time of the C call alone (buffers already laid out) is stored in timing["seconds"].
     """
+    import time as _time
     A, B, Cm = (np.asarray(q, dtype=np.float64) for q in (A, B, Cm))
     batch, n = A.shape[0], A.shape[1]
     m, r = B.shape[2], Cm.shape[1]
@@ -194,9 +197,12 @@ def qp_build_batch(A, B, Cm, W3, W4, x0, ref, f, v, threads=1, variant="", want=
         "H": np.zeros(batch * v * m * v * m) if "H" in want else None,
         "fvec": np.zeros(batch * v * m) if "fvec" in want else None,
     }
-    used = lib(variant).orc_qp_build_batch(batch, n, m, r, f, v, _p(a_), _p(b_), _p(c_), _p(w3_), _p(w4_), _p(x_),
-                                           _p(r_), _p(bufs["Phi"]), _p(bufs["Gamma"]), _p(bufs["H"]), _p(bufs["fvec"]),
-                                           threads)
+    fn = lib(variant).orc_qp_build_batch
+    t0 = _time.perf_counter()
+    used = fn(batch, n, m, r, f, v, _p(a_), _p(b_), _p(c_), _p(w3_), _p(w4_), _p(x_), _p(r_), _p(bufs["Phi"]),
+              _p(bufs["Gamma"]), _p(bufs["H"]), _p(bufs["fvec"]), threads)
+    if timing is not None:
+        timing["seconds"] = _time.perf_counter() - t0
     shapes = {"Phi": (f * r, n), "Gamma": (f * r, v * m), "H": (v * m, v * m), "fvec": (v * m, 1)}
     out = {}
     for k, buf in bufs.items():
@@ -206,7 +212,7 @@ def qp_build_batch(A, B, Cm, W3, W4, x0, ref, f, v, threads=1, variant="", want=
     return out, used
 
 
-def rollout_batch(A, B, Cm, x0, U, threads=1, variant=""):
+def rollout_batch(A, B, Cm, x0, U, threads=1, variant="", timing=None):
     """A (batch,n,n), B (batch,n,m), C (batch,r,n), x0 (batch,n), U (batch,m,T) or shared (m,T).
 
     Returns X (batch,n,T+1), Y (batch,r,T), threads used.
@@ -222,8 +228,12 @@ def rollout_batch(A, B, Cm, x0, U, threads=1, variant=""):
     x_ = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(batch, n)).reshape(-1)
     X = np.zeros(batch * n * (T + 1))
     Y = np.zeros(max(batch * r * T, 1))
-    used = lib(variant).orc_rollout_batch(batch, n, m, r, T, _p(a_), _p(b_), _p(c_), _p(x_), _p(u_), int(shared), _p(X),
-                                          _p(Y), threads)
+    import time as _time
+    fn = lib(variant).orc_rollout_batch
+    t0 = _time.perf_counter()
+    used = fn(batch, n, m, r, T, _p(a_), _p(b_), _p(c_), _p(x_), _p(u_), int(shared), _p(X), _p(Y), threads)
+    if timing is not None:
+        timing["seconds"] = _time.perf_counter() - t0
     Xo = np.transpose(X.reshape(batch, T + 1, n), (0, 2, 1)).copy()
     Yo = np.transpose(Y[:batch * r * T].reshape(batch, T, r), (0, 2, 1)).copy()
     return Xo, Yo, used
