@@ -20,20 +20,33 @@ namespace {
 
 constexpr int kLaneBlock = 64;  // one wavefront per workgroup: LDS is carved per lane, no barriers needed
 
-template <int N, int M, int R>
-__global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(QpArgs p) {
+struct LaneOut {
+    double *Phi, *Gamma, *H, *fvec;
+};
+
+// UNI: every lane of a wavefront lies in the same interleave tile (W is a multiple of 64, or W >= batch), so the
+// tile offset is wave-uniform and each access is "scalar base + 32-bit lane offset".
+template <int N, int M, int R, bool UNI>
+__global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__restrict__ gA, const double *__restrict__ gB,
+                                                             const double *__restrict__ gC,
+                                                             const double *__restrict__ gW3,
+                                                             const double *__restrict__ gW4,
+                                                             const double *__restrict__ gx0,
+                                                             const double *__restrict__ gref, LaneOut p, long long batch,
+                                                             long long W, int f, int v) {
     extern __shared__ double lds[];  // [slot][kLaneBlock]; lane t owns lds[slot * kLaneBlock + t]
     const int tid = threadIdx.x;
     const long long b = (long long)blockIdx.x * kLaneBlock + tid;
-    if (b >= p.batch) return;
-    const long long W = p.W;
-    const long long tile = b / W;
-    const long long lane = b - tile * W;
-    const int f = p.f, v = p.v;
+    if (b >= batch) return;
+    long long tile = b / W;
+    const long long lane_ll = b - tile * W;
+    if (UNI) tile = (long long)__builtin_amdgcn_readfirstlane((int)tile);
+    const unsigned lane = (unsigned)lane_ll;
     const int FR = f * R, VM = v * M;
 
     // element e of this lane's instance in an array of E elements per instance
-#define IN(ptr, E, e) ((ptr)[tile * (long long)(E) * W + (long long)(e) * W + lane])
+#define IN(ptr, E, e) (UNI ? ((ptr) + (tile * (long long)(E) + (long long)(e)) * W)[lane] \
+                           : (ptr)[tile * (long long)(E) * W + (long long)(e) * W + lane_ll])
 #define LG(k, a, c) lds[(((k) * R + (a)) * M + (c)) * kLaneBlock + tid]
 #define LZ(i, a) lds[((f * R * M) + (i) * R + (a)) * kLaneBlock + tid]
 
@@ -41,15 +54,15 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(QpArgs p) {
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int i = 0; i < N; ++i) A[i][j] = IN(p.A, N * N, j * N + i);
+        for (int i = 0; i < N; ++i) A[i][j] = IN(gA, N * N, j * N + i);
 #pragma unroll
     for (int j = 0; j < M; ++j)
 #pragma unroll
-        for (int i = 0; i < N; ++i) Bm[i][j] = IN(p.B, N * M, j * N + i);
+        for (int i = 0; i < N; ++i) Bm[i][j] = IN(gB, N * M, j * N + i);
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int i = 0; i < R; ++i) Cm[i][j] = IN(p.C, R * N, j * R + i);
+        for (int i = 0; i < R; ++i) Cm[i][j] = IN(gC, R * N, j * R + i);
 
     const bool need_g = p.Gamma || p.H || p.fvec;
     const bool need_q = p.H || p.fvec;
@@ -57,7 +70,17 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(QpArgs p) {
 #pragma unroll
     for (int j = 0; j < R; ++j)
 #pragma unroll
-        for (int i = 0; i < R; ++i) Q[i][j] = need_q ? p.W4[j * R + i] : 0.0;
+        for (int i = 0; i < R; ++i) Q[i][j] = need_q ? gW4[j * R + i] : 0.0;
+
+    // Every global load is issued before the first global store: loads and stores retire through one in-order
+    // counter, so a load placed after stores would wait for all of them.
+    double x0[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x0[i] = p.fvec ? IN(gx0, N, i) : 0.0;
+    if (p.fvec) {
+        for (int i = 0; i < FR; ++i) lds[(f * R * M + i) * kLaneBlock + tid] = IN(gref, FR, i);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no load is left in flight once the stores start
 
     // ---- Markov blocks G_k = C (A^k B), k = 0..f-1, by the recurrence w <- A w ----
     if (need_g) {
@@ -95,9 +118,6 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(QpArgs p) {
 
     // ---- Phi blocks P_i = C A^(i+1) by P <- P A, and z_i = Q (P_i x0 - ref_i) ----
     if (p.Phi || p.fvec) {
-        double x0[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) x0[i] = p.fvec ? IN(p.x0, N, i) : 0.0;
         double P[R][N];
 #pragma unroll
         for (int a = 0; a < R; ++a)
@@ -131,7 +151,7 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(QpArgs p) {
                     double acc = 0.0;
 #pragma unroll
                     for (int j = 0; j < N; ++j) acc += P[a][j] * x0[j];
-                    s[a] = acc - IN(p.ref, FR, i * R + a);
+                    s[a] = acc - LZ(i, a);  // the slot holds ref_i until z_i replaces it
                 }
 #pragma unroll
                 for (int a = 0; a < R; ++a) {
@@ -221,11 +241,11 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(QpArgs p) {
 #pragma unroll
                         for (int j = 0; j < M; ++j) {
                             const int r_up = pb * M + i, c_up = (pb + e) * M + j;
-                            IN(p.H, (long long)VM * VM, (long long)c_up * VM + r_up) = up[i][j] + p.W3[c_up * VM + r_up];
+                            IN(p.H, (long long)VM * VM, (long long)c_up * VM + r_up) = up[i][j] + gW3[c_up * VM + r_up];
                             if (e != 0) {
                                 const int r_lo = (pb + e) * M + i, c_lo = pb * M + j;
                                 IN(p.H, (long long)VM * VM, (long long)c_lo * VM + r_lo) =
-                                    lo[i][j] + p.W3[c_lo * VM + r_lo];
+                                    lo[i][j] + gW3[c_lo * VM + r_lo];
                             }
                         }
                 }
@@ -288,10 +308,10 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(QpArgs p) {
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     const int r_up = (v - 1 - e) * M + i, c_up = (v - 1) * M + j;
-                    IN(p.H, (long long)VM * VM, (long long)c_up * VM + r_up) = up[i][j] + p.W3[c_up * VM + r_up];
+                    IN(p.H, (long long)VM * VM, (long long)c_up * VM + r_up) = up[i][j] + gW3[c_up * VM + r_up];
                     if (e != 0) {
                         const int r_lo = (v - 1) * M + i, c_lo = (v - 1 - e) * M + j;
-                        IN(p.H, (long long)VM * VM, (long long)c_lo * VM + r_lo) = lo[i][j] + p.W3[c_lo * VM + r_lo];
+                        IN(p.H, (long long)VM * VM, (long long)c_lo * VM + r_lo) = lo[i][j] + gW3[c_lo * VM + r_lo];
                     }
                 }
         }
@@ -329,20 +349,30 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(QpArgs p) {
 #undef LZ
 }
 
+template <int N, int M, int R, bool UNI>
+int launch_k(const QpArgs &a, size_t lds_bytes, unsigned blocks, hipStream_t s) {
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)qp_lane_kernel<N, M, R, UNI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    LaneOut o{a.Phi, a.Gamma, a.H, a.fvec};
+    hipLaunchKernelGGL((qp_lane_kernel<N, M, R, UNI>), dim3(blocks), dim3(kLaneBlock), lds_bytes, s, a.A, a.B, a.C, a.W3,
+                       a.W4, a.x0, a.ref, o, a.batch, a.W, a.f, a.v);
+    return (int)hipGetLastError();
+}
+
 template <int N, int M, int R>
 int launch_one(const QpArgs &a, hipStream_t s) {
     const size_t slots = (size_t)a.f * R * M + (size_t)a.f * R;
     const size_t lds_bytes = slots * kLaneBlock * sizeof(double);
     if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)qp_lane_kernel<N, M, R>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
     const long long blocks = (a.batch + kLaneBlock - 1) / kLaneBlock;
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((qp_lane_kernel<N, M, R>), dim3((unsigned)blocks), dim3(kLaneBlock), lds_bytes, s, a);
-    return (int)hipGetLastError();
+    // wave-uniform tile and a lane offset whose byte offset fits 32 bits
+    const bool uni = ((a.W % kLaneBlock) == 0 || a.W >= a.batch) && a.W <= (1LL << 28);
+    return uni ? launch_k<N, M, R, true>(a, lds_bytes, (unsigned)blocks, s)
+               : launch_k<N, M, R, false>(a, lds_bytes, (unsigned)blocks, s);
 }
 
 }  // namespace
