@@ -1,8 +1,8 @@
 // Condensed-QP build for tiny plants: ONE LANE PER INSTANCE.
 //
 // For n <= 6 and one or two inputs/outputs an instance's whole working set fits a lane's registers plus a
-// few dozen LDS words, so 64 instances ride one wavefront with no idle lanes and no cross-lane traffic.  With
-// a batch-interleaved layout (W >= 64) lane l of a wave touches address base + l for every element, so every
+// few dozen words, so 64 instances ride one wavefront with no idle lanes and no cross-lane traffic.  With a
+// batch-interleaved layout (W >= 64) lane l of a wave touches address base + l for every element, so every
 // global access of the wave is one contiguous 512-byte segment.  The kernel is a pure HBM-write stream:
 // per instance it reads n^2 + n m + r n + n + f r values and writes f r n + f r v m + (v m)^2 + v m.
 //
@@ -13,6 +13,13 @@
 //   H                = Gamma^T W4 Gamma + W3, W4 = blockdiag(Q)                (:92-93), evaluated per block
 //                      diagonal as a running sum: H[a][a+d] = sum_{t <= f-1-a-d} G_(t+d)^T Q G_t
 //   fvec             = Gamma^T W4 (Phi x0 - ref)                               (:96, :125-127)
+//
+// Two instantiation styles of one body:
+//   F = V = 0   horizons are run-time values; the Markov blocks and z live in LDS, one column of slots per lane.
+//   F, V > 0    horizons are compile-time; every loop unrolls, the Markov blocks and z live in registers and the
+//               instruction stream is little more than the FMAs and the stores.
+// Addressing: every output is walked with a running pointer (wave-uniform when UNI) plus a fixed 32-bit lane
+// offset, so a store costs one vector instruction and a scalar pointer bump.
 #include "mpcx_internal.h"
 
 namespace mpcx {
@@ -20,52 +27,74 @@ namespace {
 
 constexpr int kLaneBlock = 64;  // one wavefront per workgroup: LDS is carved per lane, no barriers needed
 
+// Returns x unchanged but opaque to the optimiser at this point, so that the zero-extension of the 32-bit lane
+// offset stays next to each access and instruction selection can use the "scalar base + 32-bit vector offset"
+// addressing mode instead of forming a 64-bit vector address per access.  Emits no instruction.
+__device__ __forceinline__ unsigned keep_local(unsigned x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 struct LaneOut {
     double *Phi, *Gamma, *H, *fvec;
 };
 
 // UNI: every lane of a wavefront lies in the same interleave tile (W is a multiple of 64, or W >= batch), so the
 // tile offset is wave-uniform and each access is "scalar base + 32-bit lane offset".
-template <int N, int M, int R, bool UNI>
+// OUT: 0 = test the output pointers at run time; 15 = all four outputs are present (no tests in the stream).
+template <int N, int M, int R, bool UNI, int F, int V, int OUT>
 __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__restrict__ gA, const double *__restrict__ gB,
                                                              const double *__restrict__ gC,
                                                              const double *__restrict__ gW3,
                                                              const double *__restrict__ gW4,
                                                              const double *__restrict__ gx0,
                                                              const double *__restrict__ gref, LaneOut p, long long batch,
-                                                             long long W, int f, int v) {
+                                                             long long W, int rt_f, int rt_v) {
     extern __shared__ double lds[];  // [slot][kLaneBlock]; lane t owns lds[slot * kLaneBlock + t]
+    constexpr bool STATIC = (F > 0);
+    const bool wPhi = OUT ? true : p.Phi != nullptr, wGamma = OUT ? true : p.Gamma != nullptr;
+    const bool wH = OUT ? true : p.H != nullptr, wf = OUT ? true : p.fvec != nullptr;
     const int tid = threadIdx.x;
     const long long b = (long long)blockIdx.x * kLaneBlock + tid;
     if (b >= batch) return;
     long long tile = b / W;
     const long long lane_ll = b - tile * W;
     if (UNI) tile = (long long)__builtin_amdgcn_readfirstlane((int)tile);
-    const unsigned lane = (unsigned)lane_ll;
+    const unsigned lane_byte = UNI ? (unsigned)lane_ll * 8u : 0u;
+    const int f = STATIC ? F : rt_f, v = STATIC ? V : rt_v;
     const int FR = f * R, VM = v * M;
+    const long long stride = W * 8;  // bytes between consecutive elements of one instance
 
-    // element e of this lane's instance in an array of E elements per instance
-#define IN(ptr, E, e) (UNI ? ((ptr) + (tile * (long long)(E) + (long long)(e)) * W)[lane] \
-                           : (ptr)[tile * (long long)(E) * W + (long long)(e) * W + lane_ll])
-#define LG(k, a, c) lds[(((k) * R + (a)) * M + (c)) * kLaneBlock + tid]
-#define LZ(i, a) lds[((f * R * M) + (i) * R + (a)) * kLaneBlock + tid]
+    // base pointer of this lane's instance in an array of E elements per instance (wave-uniform when UNI)
+#define BASE(ptr, E) ((char *)(ptr) + (UNI ? tile * (long long)(E) * W : tile * (long long)(E) * W + lane_ll) * 8)
+#define AT(base, e) (*(double *)((base) + (long long)(e) * stride + lb))
+#define HERE(ptr) (*(double *)((ptr) + lb))
+
+    double greg[STATIC ? F * R * M : 1], zreg[STATIC ? F * R : 1];
+#define LG(k, a, c) \
+    (*(STATIC ? &greg[STATIC ? (((k) * R + (a)) * M + (c)) : 0] : &lds[(((k) * R + (a)) * M + (c)) * kLaneBlock + tid]))
+#define LZ(i, a) (*(STATIC ? &zreg[STATIC ? ((i) * R + (a)) : 0] : &lds[((f * R * M) + (i) * R + (a)) * kLaneBlock + tid]))
 
     double A[N][N], Bm[N][M], Cm[R][N];
+    {
+        const unsigned lb = keep_local(lane_byte);
+        const char *bA = BASE(gA, N * N), *bB = BASE(gB, N * M), *bC = BASE(gC, R * N);
 #pragma unroll
-    for (int j = 0; j < N; ++j)
+        for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int i = 0; i < N; ++i) A[i][j] = IN(gA, N * N, j * N + i);
+            for (int i = 0; i < N; ++i) A[i][j] = AT(bA, j * N + i);
 #pragma unroll
-    for (int j = 0; j < M; ++j)
+        for (int j = 0; j < M; ++j)
 #pragma unroll
-        for (int i = 0; i < N; ++i) Bm[i][j] = IN(gB, N * M, j * N + i);
+            for (int i = 0; i < N; ++i) Bm[i][j] = AT(bB, j * N + i);
 #pragma unroll
-    for (int j = 0; j < N; ++j)
+        for (int j = 0; j < N; ++j)
 #pragma unroll
-        for (int i = 0; i < R; ++i) Cm[i][j] = IN(gC, R * N, j * R + i);
+            for (int i = 0; i < R; ++i) Cm[i][j] = AT(bC, j * R + i);
+    }
 
-    const bool need_g = p.Gamma || p.H || p.fvec;
-    const bool need_q = p.H || p.fvec;
+    const bool need_g = wGamma || wH || wf;
+    const bool need_q = wH || wf;
     double Q[R][R];
 #pragma unroll
     for (int j = 0; j < R; ++j)
@@ -76,9 +105,19 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
     // counter, so a load placed after stores would wait for all of them.
     double x0[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) x0[i] = p.fvec ? IN(gx0, N, i) : 0.0;
-    if (p.fvec) {
-        for (int i = 0; i < FR; ++i) lds[(f * R * M + i) * kLaneBlock + tid] = IN(gref, FR, i);
+    for (int i = 0; i < N; ++i) x0[i] = 0.0;
+    if (wf) {
+        const unsigned lb = keep_local(lane_byte);
+        const char *bx = BASE(gx0, N), *br = BASE(gref, FR);
+#pragma unroll
+        for (int i = 0; i < N; ++i) x0[i] = AT(bx, i);
+#pragma unroll
+        for (int i = 0; i < (STATIC ? F : f); ++i)
+#pragma unroll
+            for (int a = 0; a < R; ++a) {
+                LZ(i, a) = HERE(br);
+                br += stride;
+            }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no load is left in flight once the stores start
 
@@ -89,7 +128,8 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
         for (int i = 0; i < N; ++i)
 #pragma unroll
             for (int c = 0; c < M; ++c) w[i][c] = Bm[i][c];
-        for (int k = 0; k < f; ++k) {
+#pragma unroll
+        for (int k = 0; k < (STATIC ? F : f); ++k) {
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
@@ -117,13 +157,21 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
     }
 
     // ---- Phi blocks P_i = C A^(i+1) by P <- P A, and z_i = Q (P_i x0 - ref_i) ----
-    if (p.Phi || p.fvec) {
+    if (wPhi || wf) {
+        const unsigned lb = keep_local(lane_byte);
         double P[R][N];
 #pragma unroll
         for (int a = 0; a < R; ++a)
 #pragma unroll
             for (int j = 0; j < N; ++j) P[a][j] = Cm[a][j];
-        for (int i = 0; i < f; ++i) {
+        char *pphi[N];  // one running pointer per column of Phi
+        {
+            char *bPhi = wPhi ? BASE(p.Phi, (long long)FR * N) : nullptr;
+#pragma unroll
+            for (int j = 0; j < N; ++j) pphi[j] = bPhi + (long long)j * FR * stride;
+        }
+#pragma unroll
+        for (int i = 0; i < (STATIC ? F : f); ++i) {
             double Pn[R][N];
 #pragma unroll
             for (int a = 0; a < R; ++a)
@@ -138,13 +186,16 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
             for (int a = 0; a < R; ++a)
 #pragma unroll
                 for (int j = 0; j < N; ++j) P[a][j] = Pn[a][j];
-            if (p.Phi) {
+            if (wPhi) {
 #pragma unroll
                 for (int j = 0; j < N; ++j)
 #pragma unroll
-                    for (int a = 0; a < R; ++a) IN(p.Phi, FR * N, j * FR + i * R + a) = P[a][j];
+                    for (int a = 0; a < R; ++a) {
+                        HERE(pphi[j]) = P[a][j];
+                        pphi[j] += stride;
+                    }
             }
-            if (p.fvec) {
+            if (wf) {
                 double s[R];
 #pragma unroll
                 for (int a = 0; a < R; ++a) {
@@ -164,162 +215,12 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
         }
     }
 
-    // ---- Gamma: column block k is the Markov sequence shifted down by k blocks ----
-    if (p.Gamma) {
-        for (int k = 0; k < v; ++k) {
-            const bool last = (k == v - 1);
+    // ---- fvec = Gamma^T z (before H, which reuses z's LDS slots) ----
+    if (wf) {
+        const unsigned lb = keep_local(lane_byte);
+        char *pf = BASE(p.fvec, VM);
 #pragma unroll
-            for (int c = 0; c < M; ++c) {
-                double run[R];  // running sum S for the held-input column
-#pragma unroll
-                for (int a = 0; a < R; ++a) run[a] = 0.0;
-                const long long col = (long long)(k * M + c) * FR;
-                for (int i = 0; i < f; ++i) {
-#pragma unroll
-                    for (int a = 0; a < R; ++a) {
-                        double val = 0.0;
-                        if (i >= k) {
-                            const double g = LG(i - k, a, c);
-                            run[a] += g;
-                            val = last ? run[a] : g;
-                        }
-                        IN(p.Gamma, (long long)FR * VM, col + i * R + a) = val;
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- H = Gamma^T blockdiag(Q) Gamma + W3 ----
-    if (p.H) {
-        const int nl = f - v + 1;  // rows i >= v-1: terms of every sum that involves the last block column
-        // interior block diagonals: running sums over t of G_(t+e)^T Q G_t (upper, d = +e) and
-        // G_t^T Q G_(t+e) (lower, d = -e); the block at (p, p+e) / (p+e, p) completes when t = f-1-e-p.
-        for (int e = 0; e <= v - 2; ++e) {
-            double up[M][M], lo[M][M];
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) up[i][j] = lo[i][j] = 0.0;
-            for (int t = 0; t <= f - 1 - e; ++t) {
-                double g0[R][M], g1[R][M];
-#pragma unroll
-                for (int a = 0; a < R; ++a)
-#pragma unroll
-                    for (int c = 0; c < M; ++c) {
-                        g0[a][c] = LG(t, a, c);
-                        g1[a][c] = LG(t + e, a, c);
-                    }
-                double q0[R][M], q1[R][M];  // Q g0, Q g1
-#pragma unroll
-                for (int a = 0; a < R; ++a)
-#pragma unroll
-                    for (int c = 0; c < M; ++c) {
-                        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                        for (int q = 0; q < R; ++q) {
-                            s0 += Q[a][q] * g0[q][c];
-                            s1 += Q[a][q] * g1[q][c];
-                        }
-                        q0[a][c] = s0;
-                        q1[a][c] = s1;
-                    }
-#pragma unroll
-                for (int i = 0; i < M; ++i)
-#pragma unroll
-                    for (int j = 0; j < M; ++j) {
-#pragma unroll
-                        for (int a = 0; a < R; ++a) {
-                            up[i][j] += g1[a][i] * q0[a][j];
-                            lo[i][j] += g0[a][i] * q1[a][j];
-                        }
-                    }
-                const int pb = f - 1 - e - t;  // smaller block index of the pair completed by this term
-                if (pb + e <= v - 2) {
-#pragma unroll
-                    for (int i = 0; i < M; ++i)
-#pragma unroll
-                        for (int j = 0; j < M; ++j) {
-                            const int r_up = pb * M + i, c_up = (pb + e) * M + j;
-                            IN(p.H, (long long)VM * VM, (long long)c_up * VM + r_up) = up[i][j] + gW3[c_up * VM + r_up];
-                            if (e != 0) {
-                                const int r_lo = (pb + e) * M + i, c_lo = pb * M + j;
-                                IN(p.H, (long long)VM * VM, (long long)c_lo * VM + r_lo) =
-                                    lo[i][j] + gW3[c_lo * VM + r_lo];
-                            }
-                        }
-                }
-            }
-        }
-        // last block row and column: sums over the nl rows i >= v-1 against S_j = G_0 + ... + G_j
-        for (int e = 0; e <= v - 1; ++e) {  // other block index is v-1-e
-            double up[M][M], lo[M][M];  // up: H[v-1-e][v-1], lo: H[v-1][v-1-e]
-            double S[R][M], S2[R][M];   // S_j, and S_j again as left factor when e == 0
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) up[i][j] = lo[i][j] = 0.0;
-#pragma unroll
-            for (int a = 0; a < R; ++a)
-#pragma unroll
-                for (int c = 0; c < M; ++c) S[a][c] = 0.0;
-            for (int j2 = 0; j2 < nl; ++j2) {
-                double g1[R][M];
-#pragma unroll
-                for (int a = 0; a < R; ++a)
-#pragma unroll
-                    for (int c = 0; c < M; ++c) {
-                        S[a][c] += LG(j2, a, c);
-                        g1[a][c] = LG(j2 + e, a, c);
-                        S2[a][c] = S[a][c];
-                    }
-                if (e == 0) {
-#pragma unroll
-                    for (int a = 0; a < R; ++a)
-#pragma unroll
-                        for (int c = 0; c < M; ++c) g1[a][c] = S2[a][c];
-                }
-                double qs[R][M], q1[R][M];
-#pragma unroll
-                for (int a = 0; a < R; ++a)
-#pragma unroll
-                    for (int c = 0; c < M; ++c) {
-                        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                        for (int q = 0; q < R; ++q) {
-                            s0 += Q[a][q] * S[q][c];
-                            s1 += Q[a][q] * g1[q][c];
-                        }
-                        qs[a][c] = s0;
-                        q1[a][c] = s1;
-                    }
-#pragma unroll
-                for (int i = 0; i < M; ++i)
-#pragma unroll
-                    for (int j = 0; j < M; ++j)
-#pragma unroll
-                        for (int a = 0; a < R; ++a) {
-                            up[i][j] += g1[a][i] * qs[a][j];
-                            lo[i][j] += S[a][i] * q1[a][j];
-                        }
-            }
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    const int r_up = (v - 1 - e) * M + i, c_up = (v - 1) * M + j;
-                    IN(p.H, (long long)VM * VM, (long long)c_up * VM + r_up) = up[i][j] + gW3[c_up * VM + r_up];
-                    if (e != 0) {
-                        const int r_lo = (v - 1) * M + i, c_lo = (v - 1 - e) * M + j;
-                        IN(p.H, (long long)VM * VM, (long long)c_lo * VM + r_lo) = lo[i][j] + gW3[c_lo * VM + r_lo];
-                    }
-                }
-        }
-    }
-
-    // ---- fvec = Gamma^T z ----
-    if (p.fvec) {
-        for (int k = 0; k < v; ++k) {
+        for (int k = 0; k < (STATIC ? V : v); ++k) {
             const bool last = (k == v - 1);
             double acc[M], run[R][M];
 #pragma unroll
@@ -328,7 +229,9 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
             for (int a = 0; a < R; ++a)
 #pragma unroll
                 for (int c = 0; c < M; ++c) run[a][c] = 0.0;
-            for (int i = k; i < f; ++i) {
+#pragma unroll
+            for (int i = (STATIC ? 0 : k); i < (STATIC ? F : f); ++i) {
+                if (STATIC && i < k) continue;  // constant trip count, so that the nest unrolls fully
 #pragma unroll
                 for (int a = 0; a < R; ++a) {
                     const double z = LZ(i, a);
@@ -341,38 +244,178 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
                 }
             }
 #pragma unroll
-            for (int c = 0; c < M; ++c) IN(p.fvec, VM, k * M + c) = acc[c];
+            for (int c = 0; c < M; ++c) {
+                HERE(pf) = acc[c];
+                pf += stride;
+            }
         }
     }
-#undef IN
+    // ---- Gamma: column block k is the Markov sequence shifted down by k blocks; elements in storage order ----
+    if (wGamma) {
+        const unsigned lb = keep_local(lane_byte);
+        char *pg = BASE(p.Gamma, (long long)FR * VM);
+#pragma unroll
+        for (int k = 0; k < (STATIC ? V : v); ++k) {
+            const bool last = (k == v - 1);
+#pragma unroll
+            for (int c = 0; c < M; ++c) {
+                double run[R];  // running sum S for the held-input column
+#pragma unroll
+                for (int a = 0; a < R; ++a) run[a] = 0.0;
+#pragma unroll
+                for (int i = 0; i < (STATIC ? F : f); ++i) {
+#pragma unroll
+                    for (int a = 0; a < R; ++a) {
+                        double val = 0.0;
+                        if (i >= k) {
+                            const double g = LG(i - k, a, c);
+                            run[a] += g;
+                            val = last ? run[a] : g;
+                        }
+                        HERE(pg) = val;
+                        pg += stride;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- H = Gamma^T blockdiag(Q) Gamma + W3, swept by column block from the last to the first ----
+    // Away from the last two block rows / columns H[a][b] = H[a+1][b+1] + G_(f-1-a)^T Q G_(f-1-b): the previous
+    // column block is kept (registers, or the LDS slots z no longer needs) and updated in place, and every column
+    // is stored top to bottom, so the stores walk memory in order.  The other blocks are summed directly over
+    // the rows i2 >= max(a, b), with S_j = G_0 + ... + G_j standing in for the held-input (last) column.
+    if (wH) {
+        const unsigned lb = keep_local(lane_byte);
+        double hreg[STATIC ? V * M * M : 1];
+#define HP(a, i, j) \
+    (*(STATIC ? &hreg[STATIC ? (((a) * M + (i)) * M + (j)) : 0] : &lds[((f * R * M) + ((a) * M + (i)) * M + (j)) * kLaneBlock + tid]))
+        char *bH = BASE(p.H, (long long)VM * VM);
+#pragma unroll
+        for (int bb = (STATIC ? V : v) - 1; bb >= 0; --bb) {
+#pragma unroll
+            for (int aa = 0; aa < (STATIC ? V : v); ++aa) {
+                double acc[M][M];
+                if (aa <= v - 3 && bb <= v - 3) {
+                    double qg[R][M];  // Q G_(f-1-bb)
+#pragma unroll
+                    for (int a = 0; a < R; ++a)
+#pragma unroll
+                        for (int c = 0; c < M; ++c) {
+                            double sq = 0.0;
+#pragma unroll
+                            for (int q = 0; q < R; ++q) sq += Q[a][q] * LG(f - 1 - bb, q, c);
+                            qg[a][c] = sq;
+                        }
+#pragma unroll
+                    for (int i = 0; i < M; ++i)
+#pragma unroll
+                        for (int j = 0; j < M; ++j) {
+                            double t = HP(aa + 1, i, j);
+#pragma unroll
+                            for (int a = 0; a < R; ++a) t += LG(f - 1 - aa, a, i) * qg[a][j];
+                            acc[i][j] = t;
+                        }
+                } else {
+                    const bool la = (aa == v - 1), lbk = (bb == v - 1);
+                    const int i0 = aa > bb ? aa : bb;
+                    double S[R][M];
+#pragma unroll
+                    for (int a = 0; a < R; ++a)
+#pragma unroll
+                        for (int c = 0; c < M; ++c) S[a][c] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < M; ++i)
+#pragma unroll
+                        for (int j = 0; j < M; ++j) acc[i][j] = 0.0;
+#pragma unroll
+                    for (int i2 = (STATIC ? 0 : i0); i2 < (STATIC ? F : f); ++i2) {
+                        if (STATIC && i2 < i0) continue;  // constant trip count, so that the nest unrolls fully
+                        double xa[R][M], xb[R][M];
+#pragma unroll
+                        for (int a = 0; a < R; ++a)
+#pragma unroll
+                            for (int c = 0; c < M; ++c) {
+                                if (la || lbk) S[a][c] += LG(i2 - (v - 1), a, c);
+                                xa[a][c] = la ? S[a][c] : LG(i2 - aa, a, c);
+                                xb[a][c] = lbk ? S[a][c] : LG(i2 - bb, a, c);
+                            }
+#pragma unroll
+                        for (int j = 0; j < M; ++j) {
+                            double qx[R];
+#pragma unroll
+                            for (int a = 0; a < R; ++a) {
+                                double sq = 0.0;
+#pragma unroll
+                                for (int q = 0; q < R; ++q) sq += Q[a][q] * xb[q][j];
+                                qx[a] = sq;
+                            }
+#pragma unroll
+                            for (int i = 0; i < M; ++i)
+#pragma unroll
+                                for (int a = 0; a < R; ++a) acc[i][j] += xa[a][i] * qx[a];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < M; ++i)
+#pragma unroll
+                    for (int j = 0; j < M; ++j) HP(aa, i, j) = acc[i][j];
+            }
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                char *ph = bH + (long long)(bb * M + j) * VM * stride;
+                const double *w3 = gW3 + (long long)(bb * M + j) * VM;
+#pragma unroll
+                for (int aa = 0; aa < (STATIC ? V : v); ++aa)
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+                        HERE(ph) = HP(aa, i, j) + w3[aa * M + i];
+                        ph += stride;
+                    }
+            }
+        }
+#undef HP
+    }
+
+#undef BASE
+#undef AT
+#undef HERE
 #undef LG
 #undef LZ
 }
 
-template <int N, int M, int R, bool UNI>
+template <int N, int M, int R, bool UNI, int F, int V, int OUT>
 int launch_k(const QpArgs &a, size_t lds_bytes, unsigned blocks, hipStream_t s) {
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)qp_lane_kernel<N, M, R, UNI>,
+        hipError_t e = hipFuncSetAttribute((const void *)qp_lane_kernel<N, M, R, UNI, F, V, OUT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
     LaneOut o{a.Phi, a.Gamma, a.H, a.fvec};
-    hipLaunchKernelGGL((qp_lane_kernel<N, M, R, UNI>), dim3(blocks), dim3(kLaneBlock), lds_bytes, s, a.A, a.B, a.C, a.W3,
-                       a.W4, a.x0, a.ref, o, a.batch, a.W, a.f, a.v);
+    hipLaunchKernelGGL((qp_lane_kernel<N, M, R, UNI, F, V, OUT>), dim3(blocks), dim3(kLaneBlock), lds_bytes, s, a.A, a.B, a.C,
+                       a.W3, a.W4, a.x0, a.ref, o, a.batch, a.W, a.f, a.v);
     return (int)hipGetLastError();
 }
 
 template <int N, int M, int R>
 int launch_one(const QpArgs &a, hipStream_t s) {
-    const size_t slots = (size_t)a.f * R * M + (size_t)a.f * R;
-    const size_t lds_bytes = slots * kLaneBlock * sizeof(double);
-    if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
     const long long blocks = (a.batch + kLaneBlock - 1) / kLaneBlock;
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     // wave-uniform tile and a lane offset whose byte offset fits 32 bits
     const bool uni = ((a.W % kLaneBlock) == 0 || a.W >= a.batch) && a.W <= (1LL << 28);
-    return uni ? launch_k<N, M, R, true>(a, lds_bytes, (unsigned)blocks, s)
-               : launch_k<N, M, R, false>(a, lds_bytes, (unsigned)blocks, s);
+    // register-resident specialisation for the horizon the reference's own scenario uses (main.rs:22-23)
+    const bool all = a.Phi && a.Gamma && a.H && a.fvec;
+    if constexpr (M == 1 && R == 1 && (N == 2 || N == 4)) {
+        if (uni && all && a.f == 20 && a.v == 20) return launch_k<N, M, R, true, 20, 20, 15>(a, 0, (unsigned)blocks, s);
+    }
+    const size_t zh = (size_t)a.f * R > (size_t)a.v * M * M ? (size_t)a.f * R : (size_t)a.v * M * M;
+    const size_t slots = (size_t)a.f * R * M + zh;  // Markov blocks + max(z, one column block of H)
+    const size_t lds_bytes = slots * kLaneBlock * sizeof(double);
+    if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
+    if (uni && all) return launch_k<N, M, R, true, 0, 0, 15>(a, lds_bytes, (unsigned)blocks, s);
+    return uni ? launch_k<N, M, R, true, 0, 0, 0>(a, lds_bytes, (unsigned)blocks, s)
+               : launch_k<N, M, R, false, 0, 0, 0>(a, lds_bytes, (unsigned)blocks, s);
 }
 
 }  // namespace
