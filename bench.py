@@ -77,7 +77,8 @@ def main():
     n, m, r, f, v, T = wl["n"], wl["m"], wl["r"], wl["f"], wl["v"], wl["T"]
     per_gpu = args.batch or DEFAULT_BATCH[args.workload]
     lane_native = (m <= 2 and r <= 2 and n <= 6)
-    il = args.interleave if args.interleave >= 0 else (L.INTERLEAVE_FULL if lane_native else L.INTERLEAVE_AOS)
+    # lane kernels: batch tiled in groups of 4096 instances (measured fastest); workgroup kernels: instance-major
+    il = args.interleave if args.interleave >= 0 else (4096 if lane_native else L.INTERLEAVE_AOS)
     start, count = shard.shard_range(per_gpu * world, world, rank)
     assert count == per_gpu
 

@@ -43,7 +43,7 @@ struct LaneOut {
 // tile offset is wave-uniform and each access is "scalar base + 32-bit lane offset".
 // OUT: 0 = test the output pointers at run time; 15 = all four outputs are present (no tests in the stream).
 template <int N, int M, int R, bool UNI, int F, int V, int OUT>
-__global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__restrict__ gA, const double *__restrict__ gB,
+__global__ __launch_bounds__(kLaneBlock, (F > 0 ? 4 : 1)) void qp_lane_kernel(const double *__restrict__ gA, const double *__restrict__ gB,
                                                              const double *__restrict__ gC,
                                                              const double *__restrict__ gW3,
                                                              const double *__restrict__ gW4,
@@ -70,10 +70,13 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
 #define AT(base, e) (*(double *)((base) + (long long)(e) * stride + lb))
 #define HERE(ptr) (*(double *)((ptr) + lb))
 
-    double greg[STATIC ? F * R * M : 1], zreg[STATIC ? F * R : 1];
+    // z always lives in LDS (with a compile-time horizon it is the only LDS use: F R slots per lane), which keeps
+    // the register-resident variant within 128 VGPRs, i.e. four waves per SIMD.
+    double greg[STATIC ? F * R * M : 1];
+    const int zbase = STATIC ? 0 : f * R * M;
 #define LG(k, a, c) \
     (*(STATIC ? &greg[STATIC ? (((k) * R + (a)) * M + (c)) : 0] : &lds[(((k) * R + (a)) * M + (c)) * kLaneBlock + tid]))
-#define LZ(i, a) (*(STATIC ? &zreg[STATIC ? ((i) * R + (a)) : 0] : &lds[((f * R * M) + (i) * R + (a)) * kLaneBlock + tid]))
+#define LZ(i, a) lds[(zbase + (i) * R + (a)) * kLaneBlock + tid]
 
     double A[N][N], Bm[N][M], Cm[R][N];
     {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kLaneBlock) void qp_lane_kernel(const double *__res
         const unsigned lb = keep_local(lane_byte);
         double hreg[STATIC ? V * M * M : 1];
 #define HP(a, i, j) \
-    (*(STATIC ? &hreg[STATIC ? (((a) * M + (i)) * M + (j)) : 0] : &lds[((f * R * M) + ((a) * M + (i)) * M + (j)) * kLaneBlock + tid]))
+    (*(STATIC ? &hreg[STATIC ? (((a) * M + (i)) * M + (j)) : 0] : &lds[(zbase + ((a) * M + (i)) * M + (j)) * kLaneBlock + tid]))
         char *bH = BASE(p.H, (long long)VM * VM);
 #pragma unroll
         for (int bb = (STATIC ? V : v) - 1; bb >= 0; --bb) {
@@ -407,7 +410,8 @@ int launch_one(const QpArgs &a, hipStream_t s) {
     // register-resident specialisation for the horizon the reference's own scenario uses (main.rs:22-23)
     const bool all = a.Phi && a.Gamma && a.H && a.fvec;
     if constexpr (M == 1 && R == 1 && (N == 2 || N == 4)) {
-        if (uni && all && a.f == 20 && a.v == 20) return launch_k<N, M, R, true, 20, 20, 15>(a, 0, (unsigned)blocks, s);
+        if (uni && all && a.f == 20 && a.v == 20)
+            return launch_k<N, M, R, true, 20, 20, 15>(a, (size_t)20 * R * kLaneBlock * sizeof(double), (unsigned)blocks, s);
     }
     const size_t zh = (size_t)a.f * R > (size_t)a.v * M * M ? (size_t)a.f * R : (size_t)a.v * M * M;
     const size_t slots = (size_t)a.f * R * M + zh;  // Markov blocks + max(z, one column block of H)
