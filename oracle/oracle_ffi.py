@@ -63,7 +63,7 @@ def lib(variant: str = "") -> C.CDLL:
 
 def _cm(a) -> np.ndarray:
     """Column-major flat copy of a (row, col) array."""
-    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).T).reshape(-1)
+    return np.array(np.asarray(a, dtype=np.float64).T, dtype=np.float64, order="C", copy=True).reshape(-1)
 
 
 def _p(a):
