@@ -38,6 +38,15 @@ size_t stats_scratch_bytes();
 int launch_relayout(long long batch, long long E, long long Wsrc, const double *src, long long Wdst, double *dst,
                     hipStream_t s);
 
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also waits for every outstanding global store
+// of the wave (s_waitcnt vmcnt(0)), which in a loop that stores to HBM each step serialises the loop on the store
+// latency; the kernels here never pass data between waves through global memory, so LDS ordering is all they need.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Index of element e of instance b in an array with E elements per instance and interleave width W.
 __host__ __device__ inline long long elem_index(long long b, long long e, long long E, long long W) {
     const long long tile = b / W;

@@ -101,12 +101,12 @@ __global__ __launch_bounds__(kBlock) void rollout_group_kernel(RolloutArgs p) {
         sx[lane] = x0;
         if (p.X) IN(p.X, EX, lane) = (T > 0) ? x0 : 0.0;
     }
-    __syncthreads();
+    lds_barrier();
     for (long long t = 0; t < T; ++t) {
         const double *xc = sx + (t & 1) * n;
         double *xn = sx + ((t + 1) & 1) * n;
         if (lane < m) su[lane] = p.u_shared ? p.U[t * m + lane] : IN(p.U, EU, t * m + lane);
-        __syncthreads();
+        lds_barrier();
         if (lane < n) {
             double s = 0.0;
             for (int j = 0; j < n; ++j) s += sA[j * n + lane] * xc[j];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void rollout_group_kernel(RolloutArgs p) {
             for (int j = 0; j < n; ++j) y += sC[j * r + lane] * xc[j];
             IN(p.Y, EY, t * r + lane) = y;
         }
-        __syncthreads();
+        lds_barrier();
     }
 #undef IN
 }

@@ -48,7 +48,9 @@ def test_lane_kernel_shapes_and_held_input(ctx, n, m, r, f, v):
 
 
 @pytest.mark.parametrize("n,m,r,f,v", [(12, 4, 12, 10, 10), (12, 4, 12, 9, 4), (8, 2, 2, 40, 40), (8, 2, 2, 30, 7),
-                                       (7, 3, 5, 6, 6), (9, 1, 1, 12, 2), (16, 5, 3, 5, 1), (10, 2, 4, 3, 3)])
+                                       (7, 3, 5, 6, 6), (9, 1, 1, 12, 2), (16, 5, 3, 5, 1), (10, 2, 4, 3, 3),
+                                       (8, 4, 4, 11, 11), (7, 3, 3, 9, 5), (9, 2, 4, 8, 8), (9, 1, 1, 300, 300),
+                                       (8, 2, 2, 150, 150), (8, 2, 2, 140, 131), (20, 2, 2, 6, 6), (12, 4, 12, 3, 2)])
 def test_workgroup_kernel_shapes(ctx, n, m, r, f, v):
     rng = np.random.default_rng(n * 7 + m * 5 + r * 3 + f + v)
     batch = 9
