@@ -23,7 +23,7 @@
 #include "mpcx_internal.h"
 
 namespace mpcx {
-inline namespace dbg_open {
+namespace {
 
 constexpr int kCompute = 256;            // threads that compute and store
 constexpr int kWgBlock = kCompute + 64;  // + one loader wave
@@ -535,16 +535,3 @@ int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s) {
 }
 
 }  // namespace mpcx
-
-extern "C" int mpcx_debug_occ(int which, int lds_bytes) {
-    int nb = -1;
-    hipError_t e;
-    if (which == 0) {
-        (void)hipFuncSetAttribute((const void *)mpcx::qp_wg_kernel<4, 12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpcx::qp_wg_kernel<4, 12, 1>, 320, lds_bytes);
-    } else {
-        (void)hipFuncSetAttribute((const void *)mpcx::qp_wg_kernel<2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mpcx::qp_wg_kernel<2, 2, 4>, 320, lds_bytes);
-    }
-    return e == hipSuccess ? nb : -(int)e;
-}
