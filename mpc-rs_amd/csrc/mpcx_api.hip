@@ -171,6 +171,21 @@ int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, co
     hipStream_t s = (hipStream_t)stream;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (d->hessian_algo != MPCX_HESSIAN_AUTO && d->hessian_algo != MPCX_HESSIAN_CONTRACT &&
+        d->hessian_algo != MPCX_HESSIAN_STRUCTURED)
+        return fail(ctx, MPCX_ERR_DIMS, "unknown hessian_algo %d", d->hessian_algo);
+    if (H && d->hessian_algo == MPCX_HESSIAN_CONTRACT) {
+        // dense contraction on the matrix cores: H from its own kernel, everything else from the build kernels
+        if (W != 1)
+            return fail(ctx, MPCX_ERR_LAYOUT, "hessian_algo = CONTRACT takes instance-major data (interleave = 1)");
+        rc = launch_hessian_mfma(a, s);
+        if (rc == MPCX_ERR_UNSUPPORTED)
+            return fail(ctx, rc, "hessian_algo = CONTRACT: n=%d m=%d r=%d f=%d v=%d weights_mode=%d exceeds the kernel's on-chip working set",
+                        d->n, d->m, d->r, d->f, d->v, d->weights_mode);
+        if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "hessian_mfma launch");
+        a.H = nullptr;
+        if (!Phi && !Gamma && !fvec) return MPCX_OK;
+    }
     rc = launch_qp_lane(a, s);
     if (rc == MPCX_ERR_UNSUPPORTED) rc = launch_qp_wg(a, d->hessian_algo, s);
     if (rc == MPCX_ERR_LAYOUT)

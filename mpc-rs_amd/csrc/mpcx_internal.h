@@ -30,6 +30,7 @@ struct RolloutArgs {
 // what that kernel family holds on chip (the caller then tries the next family).
 int launch_qp_lane(const QpArgs &a, hipStream_t s);
 int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s);
+int launch_hessian_mfma(const QpArgs &a, hipStream_t s);
 int launch_rollout_lane(const RolloutArgs &a, hipStream_t s);
 int launch_rollout_group(const RolloutArgs &a, hipStream_t s);
 int launch_stats(const double *buf, long long count, mpcx_stats *out_dev, void *scratch, size_t scratch_bytes,

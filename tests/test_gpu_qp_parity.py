@@ -111,3 +111,30 @@ def test_argument_errors(ctx):
     with pytest.raises(ffi.MpcxError) as e:
         _run(ctx, big, 0)  # workgroup kernels take instance-major data only
     assert e.value.code == ffi.ERR_LAYOUT
+
+
+@pytest.mark.parametrize("n,m,r,f,v", [(12, 4, 12, 10, 10), (12, 4, 12, 9, 4), (8, 2, 2, 40, 40), (8, 2, 2, 30, 7),
+                                       (7, 3, 5, 6, 6), (4, 1, 1, 20, 20), (9, 1, 1, 70, 70), (16, 5, 3, 5, 1),
+                                       (8, 2, 2, 150, 150), (6, 2, 2, 33, 17)])
+def test_hessian_contraction_on_matrix_cores(ctx, n, m, r, f, v):
+    """hessian_algo = CONTRACT: H = Gamma^T (W4 Gamma) + W3 through the FP64 MFMA kernel; the other outputs unchanged."""
+    rng = np.random.default_rng(n * 11 + m * 5 + r * 3 + f + v)
+    batch = 5
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    data = dict(A=A, B=B, C=C, W3=rng.standard_normal((v * m, v * m)), Q=rng.standard_normal((r, r)),
+                x0=rng.standard_normal((batch, n)), ref=rng.standard_normal((batch, f * r)), f=f, v=v)
+    want = oracle_qp(orc, data)
+    got = _run(ctx, data, 1, hessian_algo=ffi.HESSIAN_CONTRACT)
+    for k in ("Phi", "Gamma", "H", "fvec"):
+        assert_close(got[k], want[k], f"contract n{n} m{m} r{r} f{f} v{v} {k}")
+    only_h = _run(ctx, data, 1, want=("H",), hessian_algo=ffi.HESSIAN_CONTRACT)
+    assert np.array_equal(only_h["H"], got["H"])
+    structured = _run(ctx, data, 1, want=("H",), hessian_algo=ffi.HESSIAN_STRUCTURED)
+    assert_close(structured["H"], got["H"], "structured vs contraction")
+
+
+def test_hessian_contraction_needs_instance_major(ctx):
+    data = synth.make_batch("two_mass", 64)
+    with pytest.raises(ffi.MpcxError) as e:
+        _run(ctx, data, 0, hessian_algo=ffi.HESSIAN_CONTRACT)
+    assert e.value.code == ffi.ERR_LAYOUT
