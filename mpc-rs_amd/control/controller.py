@@ -1,0 +1,115 @@
+"""Mirror of src/control/controller.rs (module ``mpc``): the lifted matrices, Hessian and rollout step run on the GPU
+through the C ABI; the weights of ``new`` are built on the host exactly as the reference builds them."""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import ffi
+from .model import DiscreteStateSpaceModel
+from .simulator import context
+
+
+def _block_of(mat_w4: np.ndarray, f: int, r: int):
+    """The r x r block if W4 is block-diagonal with one repeated block (what Controller::new builds), else None."""
+    q = mat_w4[:r, :r]
+    rebuilt = np.zeros_like(mat_w4)
+    for i in range(f):
+        rebuilt[i * r:(i + 1) * r, i * r:(i + 1) * r] = q
+    return q if np.array_equal(rebuilt, mat_w4) else None
+
+
+def _try_inverse(h: np.ndarray):
+    """nalgebra's try_inverse semantics on the host: LU with partial pivoting, None on an exactly zero pivot."""
+    n = h.shape[0]
+    lu = np.array(h, dtype=np.float64, copy=True)
+    perm = np.arange(n)
+    for k in range(n):
+        piv = k + int(np.argmax(np.abs(lu[k:, k])))
+        if lu[piv, k] == 0.0 or not np.isfinite(lu[piv, k]):
+            return None
+        if piv != k:
+            lu[[k, piv]] = lu[[piv, k]]
+            perm[[k, piv]] = perm[[piv, k]]
+        lu[k + 1:, k] /= lu[k, k]
+        lu[k + 1:, k + 1:] -= np.outer(lu[k + 1:, k], lu[k, k + 1:])
+    inv = np.eye(n)[perm]
+    for k in range(n):  # forward substitution, unit lower
+        inv[k + 1:] -= np.outer(lu[k + 1:, k], inv[k])
+    for k in range(n - 1, -1, -1):  # back substitution
+        inv[k] /= lu[k, k]
+        inv[:k] -= np.outer(lu[:k, k], inv[k])
+    return inv
+
+
+class mpc:  # noqa: N801  (module name in the reference)
+    class Controller:
+        def __init__(self, model, f, mat_o, gain_matrix, desired_ctrl_traj_total):
+            self._model = model
+            self._f = f
+            self._mat_o = mat_o
+            self._gain_matrix = gain_matrix
+            self.desired_ctrl_traj_total = desired_ctrl_traj_total  # pub field, controller.rs:12
+
+        @staticmethod
+        def lifted_and_hessian(mat_a, mat_b, mat_c, f: int, v: int, mat_w3, mat_w4):
+            """(O, M, H) on the GPU: controller.rs:28-93 up to the matrix handed to try_inverse."""
+            mat_a, mat_b, mat_c = (np.asarray(x, dtype=np.float64) for x in (mat_a, mat_b, mat_c))
+            mat_w3, mat_w4 = np.asarray(mat_w3, dtype=np.float64), np.asarray(mat_w4, dtype=np.float64)
+            n, m, r = mat_a.shape[0], mat_b.shape[1], mat_c.shape[0]
+            if mat_a.shape != (n, n) or mat_b.shape[0] != n or mat_c.shape[1] != n:
+                raise ValueError("Matrix multiplication dimensions mismatch.")  # nalgebra's panic at :43 / :61
+            if mat_w3.shape != (v * m, v * m) or mat_w4.shape != (f * r, f * r):
+                raise ValueError("Matrix multiplication dimensions mismatch.")  # :92-93
+            q = _block_of(mat_w4, f, r)
+            mode, w4 = (ffi.WEIGHTS_BLOCK, q) if q is not None else (ffi.WEIGHTS_DENSE, mat_w4)
+            out = context().qp_build(mat_a[None], mat_b[None], mat_c[None], f, v, W3=mat_w3, W4=w4, weights_mode=mode,
+                                     want=("Phi", "Gamma", "H"))
+            return out["Phi"][0], out["Gamma"][0], out["H"][0]
+
+        @staticmethod
+        def form_lifted_matrices(mat_a, mat_b, mat_c, f: int, v: int, mat_w3, mat_w4):
+            """controller.rs:16-99: returns (mat_o, mat_m, gain_matrix); raises RuntimeError("Matrix inversion failed")
+            where the reference returns that Err (:93-95)."""
+            mat_o, mat_m, h = mpc.Controller.lifted_and_hessian(mat_a, mat_b, mat_c, f, v, mat_w3, mat_w4)
+            tmp2 = _try_inverse(h)
+            if tmp2 is None:
+                raise RuntimeError("Matrix inversion failed")
+            gain_matrix = tmp2 @ mat_m.T @ np.asarray(mat_w4, dtype=np.float64)  # :96
+            return mat_o, mat_m, gain_matrix
+
+        @classmethod
+        def new(cls, model: DiscreteStateSpaceModel, f: int, v: int, q0: float, q_other: float, pred_weight: float,
+                desired_ctrl_traj: np.ndarray) -> "mpc.Controller":
+            """controller.rs:137-207."""
+            m = model.get_mat_b().shape[1]
+            r = model.get_mat_c().shape[0]
+            w1 = np.zeros((v * m, v * m))  # :149-161
+            w2 = np.zeros((v * m, v * m))  # :164-175
+            for i in range(v):
+                w1[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.eye(m)
+                if i >= 1:
+                    w1[i * m:(i + 1) * m, (i - 1) * m:i * m] = -np.eye(m)
+                w2[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.full((m, m), q0 if i == 0 else q_other)
+            w3 = w1.T @ (w2 @ w1)  # :177
+            w4 = np.zeros((f * r, f * r))  # :179-185
+            for i in range(f):
+                w4[i * r:(i + 1) * r, i * r:(i + 1) * r] = np.full((r, r), pred_weight)
+            mat_o, _, gain = cls.form_lifted_matrices(model.get_mat_a(), model.get_mat_b(), model.get_mat_c(), f, v, w3, w4)
+            return cls(model, f, mat_o, gain, np.array(desired_ctrl_traj, dtype=np.float64, copy=True))
+
+        def propagate_dynamics(self, control_input: np.ndarray, state: np.ndarray):
+            """controller.rs:101-115: (x_next, y) with y the output at the current state; one rollout step on the GPU."""
+            a, b, c = self._model.get_mat_a(), self._model.get_mat_b(), self._model.get_mat_c()
+            u = np.asarray(control_input, dtype=np.float64).reshape(1, -1, 1)
+            out = context().rollout(a[None], b[None], c[None], np.asarray(state, dtype=np.float64).reshape(1, -1), u)
+            return out["X"][0, :, 1].copy(), out["Y"][0, :, 0].copy()
+
+        def compute_control_input(self, timestep: int, state: np.ndarray) -> np.ndarray:
+            """controller.rs:117-135: first element of gain (traj[t..t+f] - O x), as a 1-vector (one input, one output)."""
+            traj = self.desired_ctrl_traj_total
+            if timestep + self._f > traj.shape[0]:
+                raise IndexError("Matrix slicing out of bounds.")  # view_range panics at :121
+            seg = traj[timestep:timestep + self._f, :]
+            vec_s = seg - (self._mat_o @ np.asarray(state, dtype=np.float64).reshape(-1, 1))  # :125-127
+            seq = self._gain_matrix @ vec_s  # :130
+            return np.array([seq[0, 0]])  # :131-134

@@ -1,0 +1,69 @@
+"""The reference's own scenario (src/main.rs:14-71) through the host mirror of its API, on the GPU, against the oracle
+and against the curves read off the reference's charts."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_close
+from mpc_rs_amd.control import controller, model, simulator, trajectory
+from oracle import oracle_ffi as orc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _trace_ok(name, y, tol):
+    t = json.load(open(os.path.join(GOLDEN, name)))
+    kk, hp = np.arange(len(y)), t["x_halfpixel"]
+    for x, lo, hi in zip(t["x"], t["y_lo"], t["y_hi"]):
+        seg = [np.interp(min(max(x + d, 0), len(y) - 1), kk, y) for d in (-hp, 0.0, hp)]
+        assert max(seg) >= lo - tol and min(seg) <= hi + tol, (name, x)
+
+
+def test_main_rs_scenario(ctx):
+    sampling_dt = 0.05
+    mdl = model.dc_motor.Model(model.dc_motor.Parameters(), sampling_dt)
+    step_response, step, _ = simulator.step(mdl, 10.0)
+    assert step_response.shape == (1, 200) and step.shape == (1, 200)
+    _trace_ok("step_response_png_trace.json", step_response[0], 5e-5)
+    assert simulator.compute_system_response(mdl, step, np.zeros(2)) == list(step_response[0])
+
+    f = v = 20
+    time_steps = 300
+    traj = trajectory.generate_pulse_trajectory(time_steps)
+    mpc = controller.mpc.Controller.new(mdl, f, v, 0.0000000011, 0.0001, 10.0, traj)
+    states = [np.zeros(2)]
+    outputs = [mdl.get_mat_c() @ states[0]]
+    inputs = []
+    for t in range(time_steps - f):
+        u = mpc.compute_control_input(t, states[t])
+        nxt, y = mpc.propagate_dynamics(u, states[t])
+        states.append(nxt)
+        outputs.append(y)
+        inputs.append(u[0])
+    outputs = np.array(outputs)[:, 0]
+    _trace_ok("control_png_trace.json", outputs, 2e-3)
+
+    A, B, C = mdl.get_mat_a(), mdl.get_mat_b(), mdl.get_mat_c()
+    _, _, w3, w4 = orc.controller_weights(1, 1, f, v, 1.1e-9, 1e-4, 10.0)
+    st, O, M, H, G = orc.form_lifted_matrices(A, B, C, f, v, w3, w4)
+    S, Out, In = orc.closed_loop(A, B, C, f, v, O, G, traj, time_steps - f, np.zeros(2))
+    assert_close(np.array(inputs)[None], In[None], "closed-loop inputs", tol=1e-8)   # through H^-1, cond(H) ~ 268
+    assert_close(outputs[None], Out, "closed-loop outputs", tol=1e-8)
+    o2, m2, g2 = controller.mpc.Controller.form_lifted_matrices(A, B, C, f, v, w3, w4)
+    assert_close(o2[None], O[None], "mat_o")
+    assert_close(m2[None], M[None], "mat_m")
+    assert_close(g2[None], G[None], "gain", tol=1e-8)
+
+
+def test_error_behaviour(ctx):
+    with pytest.raises(ValueError):
+        trajectory.generate_pulse_trajectory(301)
+    A, C = 0.5 * np.eye(2), np.eye(2)
+    B = np.ones((2, 2))
+    with pytest.raises(RuntimeError, match="Matrix inversion failed"):
+        controller.mpc.Controller.form_lifted_matrices(A, B, C, 2, 2, np.zeros((4, 4)), np.eye(4))
+    with pytest.raises(ValueError):
+        controller.mpc.Controller.form_lifted_matrices(A, B, C, 2, 2, np.zeros((3, 3)), np.eye(4))
