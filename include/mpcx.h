@@ -125,6 +125,26 @@ int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, 
                          const double *x0, const double *U, double *X, double *Y, void *stream);
 
 /*
+ * Batched solve with the condensed Hessian (LU with partial pivoting per instance, as nalgebra's try_inverse).
+ *   mpcx_qp_solve:  u_seq (v m per instance) = -H^-1 fvec: the optimal input sequence; its first m entries are the
+ *                   move the reference applies (controller.rs:130-134 with gain s = -H^-1 fvec).
+ *   mpcx_qp_gain:   gain ((v m) x (f r) per instance) = H^-1 Gamma^T W4, the reference's gain_matrix
+ *                   (controller.rs:93-96); W4 is the r x r block (MPCX_WEIGHTS_BLOCK only).
+ * `info` (int32 per instance, plain array of `batch` entries, may be NULL) is 0 on success and 1 where the reference
+ * returns Err("Matrix inversion failed") (controller.rs:93-95): an exactly zero or non-finite pivot; the outputs of
+ * such an instance are NaN.  The call itself still returns MPCX_OK.  H, fvec, Gamma, u_seq, gain use dims->interleave.
+ * Limit: (v m) (v m + columns of the right-hand side) doubles must fit the 160 KB of LDS, else MPCX_ERR_UNSUPPORTED.
+ */
+int mpcx_qp_solve_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *fvec, double *u_seq,
+                      int32_t *info);
+int mpcx_qp_solve_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *fvec, double *u_seq,
+                          int32_t *info, void *stream);
+int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *Gamma, const double *W4,
+                     double *gain, int32_t *info);
+int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *Gamma, const double *W4,
+                         double *gain, int32_t *info, void *stream);
+
+/*
  * Reduces `count` f64 values at device pointer `buf` to one mpcx_stats record written to device memory
  * `out_dev` (no counterpart in the reference: it is what sharded runs gather instead of the results).
  */

@@ -174,7 +174,19 @@ int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, co
     if (d->hessian_algo != MPCX_HESSIAN_AUTO && d->hessian_algo != MPCX_HESSIAN_CONTRACT &&
         d->hessian_algo != MPCX_HESSIAN_STRUCTURED)
         return fail(ctx, MPCX_ERR_DIMS, "unknown hessian_algo %d", d->hessian_algo);
-    if (H && d->hessian_algo == MPCX_HESSIAN_CONTRACT) {
+    if (d->weights_mode == MPCX_WEIGHTS_DENSE && (H || fvec)) {
+        // dense W4: H and fvec from the column-by-column kernel, Phi and Gamma from the build kernels
+        if (W != 1) return fail(ctx, MPCX_ERR_LAYOUT, "weights_mode = DENSE takes instance-major data (interleave = 1)");
+        rc = launch_qp_dense(a, s);
+        if (rc == MPCX_ERR_UNSUPPORTED)
+            return fail(ctx, rc, "weights_mode = DENSE: n=%d m=%d r=%d f=%d v=%d exceeds the kernel's on-chip working set",
+                        d->n, d->m, d->r, d->f, d->v);
+        if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "qp_dense launch");
+        a.H = nullptr;
+        a.fvec = nullptr;
+        if (!Phi && !Gamma) return MPCX_OK;
+    }
+    if (a.H && d->hessian_algo == MPCX_HESSIAN_CONTRACT) {
         // dense contraction on the matrix cores: H from its own kernel, everything else from the build kernels
         if (W != 1)
             return fail(ctx, MPCX_ERR_LAYOUT, "hessian_algo = CONTRACT takes instance-major data (interleave = 1)");
@@ -315,6 +327,105 @@ int mpcx_rollout_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const d
     for (int i = 0; i < 2; ++i)
         if (hout[i] && nout[i] > 0)
             HIP_TRY(ctx, hipMemcpyAsync(hout[i], dout[i], (size_t)nout[i] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCX_OK;
+}
+
+int mpcx_qp_solve_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *fvec, double *u_seq,
+                          int32_t *info, void *stream) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->v < 1) return fail(ctx, MPCX_ERR_DIMS, "need v >= 1");
+    if (d->batch == 0) return MPCX_OK;
+    if (!H || !fvec || !u_seq) return fail(ctx, MPCX_ERR_NULL, "H, fvec and u_seq are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = launch_qp_solve(H, fvec, u_seq, info, d->batch, W, d->v * d->m, (hipStream_t)stream);
+    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "solve: v m = %d does not fit LDS", d->v * d->m);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "solve launch");
+    return MPCX_OK;
+}
+
+int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *Gamma, const double *W4,
+                         double *gain, int32_t *info, void *stream) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->f < 1 || d->v < 1 || d->v > d->f) return fail(ctx, MPCX_ERR_DIMS, "need f >= 1 and 1 <= v <= f");
+    if (d->weights_mode != MPCX_WEIGHTS_BLOCK) return fail(ctx, MPCX_ERR_UNSUPPORTED, "gain: W4 must be the r x r block");
+    if (d->batch == 0) return MPCX_OK;
+    if (!H || !Gamma || !W4 || !gain) return fail(ctx, MPCX_ERR_NULL, "H, Gamma, W4 and gain are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = launch_qp_gain(H, Gamma, W4, gain, info, d->batch, W, d->m, d->r, d->f, d->v, (hipStream_t)stream);
+    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "gain: (v m)(v m + f r) = %d x %d does not fit LDS", d->v * d->m, d->v * d->m + d->f * d->r);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "gain launch");
+    return MPCX_OK;
+}
+
+namespace {
+// host-pointer wrapper shared by solve and gain: inputs in[i] (elements nin[i]) up, outputs down, info down
+int host_roundtrip(mpcx_ctx *ctx, int n_in, const double *const *hin, const long long *nin, double *hout, long long nout,
+                   int32_t *hinfo, long long batch, const double **din, double **dout, int32_t **dinfo) {
+    size_t off[4], total = 0;
+    for (int i = 0; i < n_in; ++i) { off[i] = total; total += align256((size_t)nin[i] * sizeof(double)); }
+    const size_t off_out = total; total += align256((size_t)nout * sizeof(double));
+    const size_t off_info = total; total += align256((size_t)batch * sizeof(int32_t));
+    int rc = ensure_work(ctx, total);
+    if (rc != MPCX_OK) return rc;
+    char *base = (char *)ctx->work;
+    for (int i = 0; i < n_in; ++i) {
+        din[i] = (const double *)(base + off[i]);
+        HIP_TRY(ctx, hipMemcpyAsync((void *)din[i], hin[i], (size_t)nin[i] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    *dout = (double *)(base + off_out);
+    *dinfo = hinfo ? (int32_t *)(base + off_info) : nullptr;
+    (void)hout;
+    return MPCX_OK;
+}
+}  // namespace
+
+int mpcx_qp_solve_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *fvec, double *u_seq, int32_t *info) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->batch == 0) return MPCX_OK;
+    if (!H || !fvec || !u_seq) return fail(ctx, MPCX_ERR_NULL, "H, fvec and u_seq are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long vm = (long long)d->v * d->m;
+    const double *hin[2] = {H, fvec};
+    const long long nin[2] = {mpcx_array_elems(d->batch, d->interleave, vm * vm), mpcx_array_elems(d->batch, d->interleave, vm)};
+    const long long nout = nin[1];
+    const double *din[2]; double *dout; int32_t *dinfo;
+    rc = host_roundtrip(ctx, 2, hin, nin, u_seq, nout, info, d->batch, din, &dout, &dinfo);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_qp_solve_f64_dev(ctx, d, din[0], din[1], dout, dinfo, (void *)ctx->stream);
+    if (rc != MPCX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    HIP_TRY(ctx, hipMemcpyAsync(u_seq, dout, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (info) HIP_TRY(ctx, hipMemcpyAsync(info, dinfo, (size_t)d->batch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCX_OK;
+}
+
+int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *Gamma, const double *W4, double *gain,
+                     int32_t *info) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->batch == 0) return MPCX_OK;
+    if (!H || !Gamma || !W4 || !gain) return fail(ctx, MPCX_ERR_NULL, "H, Gamma, W4 and gain are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long vm = (long long)d->v * d->m, fr = (long long)d->f * d->r;
+    const double *hin[3] = {H, Gamma, W4};
+    const long long nin[3] = {mpcx_array_elems(d->batch, d->interleave, vm * vm), mpcx_array_elems(d->batch, d->interleave, fr * vm),
+                              (long long)d->r * d->r};
+    const long long nout = mpcx_array_elems(d->batch, d->interleave, vm * fr);
+    const double *din[3]; double *dout; int32_t *dinfo;
+    rc = host_roundtrip(ctx, 3, hin, nin, gain, nout, info, d->batch, din, &dout, &dinfo);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_qp_gain_f64_dev(ctx, d, din[0], din[1], din[2], dout, dinfo, (void *)ctx->stream);
+    if (rc != MPCX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    HIP_TRY(ctx, hipMemcpyAsync(gain, dout, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (info) HIP_TRY(ctx, hipMemcpyAsync(info, dinfo, (size_t)d->batch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MPCX_OK;
 }

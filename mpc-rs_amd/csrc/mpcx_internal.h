@@ -31,6 +31,11 @@ struct RolloutArgs {
 int launch_qp_lane(const QpArgs &a, hipStream_t s);
 int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s);
 int launch_hessian_mfma(const QpArgs &a, hipStream_t s);
+int launch_qp_dense(const QpArgs &a, hipStream_t s);
+int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *info, long long batch, long long W, int vm,
+                    hipStream_t s);
+int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double *gain, int *info, long long batch,
+                   long long W, int m, int r, int f, int v, hipStream_t s);
 int launch_rollout_lane(const RolloutArgs &a, hipStream_t s);
 int launch_rollout_group(const RolloutArgs &a, hipStream_t s);
 int launch_stats(const double *buf, long long count, mpcx_stats *out_dev, void *scratch, size_t scratch_bytes,

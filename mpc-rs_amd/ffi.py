@@ -25,6 +25,7 @@ HESSIAN_AUTO, HESSIAN_CONTRACT, HESSIAN_STRUCTURED = 0, 1, 2
 EXPORTS = (
     "mpcx_version", "mpcx_array_elems", "mpcx_create", "mpcx_destroy", "mpcx_last_error",
     "mpcx_qp_build_f64", "mpcx_qp_build_f64_dev", "mpcx_rollout_f64", "mpcx_rollout_f64_dev",
+    "mpcx_qp_solve_f64", "mpcx_qp_solve_f64_dev", "mpcx_qp_gain_f64", "mpcx_qp_gain_f64_dev",
     "mpcx_stats_f64_dev", "mpcx_stats_f64", "mpcx_relayout_f64_dev",
 )
 
@@ -84,6 +85,14 @@ def lib() -> C.CDLL:
     lb.mpcx_rollout_f64.restype = C.c_int
     lb.mpcx_rollout_f64_dev.argtypes = [vp, C.POINTER(Dims)] + [dp] * 7 + [vp]
     lb.mpcx_rollout_f64_dev.restype = C.c_int
+    lb.mpcx_qp_solve_f64.argtypes = [vp, C.POINTER(Dims), dp, dp, dp, vp]
+    lb.mpcx_qp_solve_f64.restype = C.c_int
+    lb.mpcx_qp_solve_f64_dev.argtypes = [vp, C.POINTER(Dims), dp, dp, dp, vp, vp]
+    lb.mpcx_qp_solve_f64_dev.restype = C.c_int
+    lb.mpcx_qp_gain_f64.argtypes = [vp, C.POINTER(Dims), dp, dp, dp, dp, vp]
+    lb.mpcx_qp_gain_f64.restype = C.c_int
+    lb.mpcx_qp_gain_f64_dev.argtypes = [vp, C.POINTER(Dims), dp, dp, dp, dp, vp, vp]
+    lb.mpcx_qp_gain_f64_dev.restype = C.c_int
     lb.mpcx_stats_f64_dev.argtypes = [vp, dp, i64, vp, vp]
     lb.mpcx_stats_f64_dev.restype = C.c_int
     lb.mpcx_stats_f64.argtypes = [vp, dp, i64, C.POINTER(Stats)]
@@ -184,6 +193,35 @@ class Context:
             if outs[k] is not None:
                 res[k] = L.unpack(outs[k], batch, rows, cols, interleave)
         return res
+
+    def qp_solve_dev(self, dims: Dims, H, fvec, u_seq, info, stream=0):
+        self._check(self._lib.mpcx_qp_solve_f64_dev(self._h, C.byref(dims), H, fvec, u_seq, info, stream))
+
+    def qp_gain_dev(self, dims: Dims, H, Gamma, W4, gain, info, stream=0):
+        self._check(self._lib.mpcx_qp_gain_f64_dev(self._h, C.byref(dims), H, Gamma, W4, gain, info, stream))
+
+    def qp_solve(self, H, fvec, m, interleave=L.INTERLEAVE_AOS):
+        """H (batch, vm, vm), fvec (batch, vm[, 1]) -> (u_seq (batch, vm), info (batch,) int32): u_seq = -H^-1 fvec."""
+        H = np.asarray(H, dtype=np.float64)
+        batch, vm = H.shape[0], H.shape[1]
+        d = make_dims(1, m, 1, vm // m, vm // m, batch, 0, interleave)
+        hb = L.pack(H, interleave)
+        fb = L.pack(np.asarray(fvec, dtype=np.float64).reshape(batch, vm, 1), interleave)
+        out = np.full(max(L.array_elems(batch, interleave, vm), 1), np.nan)
+        info = np.full(max(batch, 1), -1, dtype=np.int32)
+        self._check(self._lib.mpcx_qp_solve_f64(self._h, C.byref(d), _hp(hb), _hp(fb), _hp(out), info.ctypes.data_as(C.c_void_p)))
+        return L.unpack(out, batch, vm, 1, interleave)[:, :, 0], info[:batch]
+
+    def qp_gain(self, H, Gamma, Q, m, r, f, v, interleave=L.INTERLEAVE_AOS):
+        """gain (batch, vm, fr) = H^-1 Gamma^T blockdiag(Q), and info (batch,)."""
+        H = np.asarray(H, dtype=np.float64)
+        batch = H.shape[0]
+        d = make_dims(1, m, r, f, v, batch, 0, interleave)
+        hb, gb, qb = L.pack(H, interleave), L.pack(np.asarray(Gamma, dtype=np.float64), interleave), L.colmajor(Q)
+        out = np.full(max(L.array_elems(batch, interleave, v * m * f * r), 1), np.nan)
+        info = np.full(max(batch, 1), -1, dtype=np.int32)
+        self._check(self._lib.mpcx_qp_gain_f64(self._h, C.byref(d), _hp(hb), _hp(gb), _hp(qb), _hp(out), info.ctypes.data_as(C.c_void_p)))
+        return L.unpack(out, batch, v * m, f * r, interleave), info[:batch]
 
     def rollout(self, A, B, Cm, x0, U, interleave=L.INTERLEAVE_AOS, want=("X", "Y")):
         """U is (batch, m, T) or, shared by all instances, (m, T).  Returns X (batch, n, T+1), Y (batch, r, T)."""

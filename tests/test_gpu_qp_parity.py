@@ -138,3 +138,20 @@ def test_hessian_contraction_needs_instance_major(ctx):
     with pytest.raises(ffi.MpcxError) as e:
         _run(ctx, data, 0, hessian_algo=ffi.HESSIAN_CONTRACT)
     assert e.value.code == ffi.ERR_LAYOUT
+
+
+@pytest.mark.parametrize("n,m,r,f,v", [(2, 1, 1, 20, 20), (4, 2, 3, 9, 4), (12, 4, 12, 6, 6), (8, 2, 2, 25, 25), (3, 1, 2, 7, 1),
+                                       (5, 1, 1, 1, 1)])
+def test_dense_output_weight(ctx, n, m, r, f, v):
+    """weights_mode = DENSE: an arbitrary dense W4, the literal signature of form_lifted_matrices (controller.rs:23)."""
+    rng = np.random.default_rng(n + 10 * m + 100 * r + f * v)
+    batch = 4
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    W3, W4 = rng.standard_normal((v * m, v * m)), rng.standard_normal((f * r, f * r))
+    x0, ref = rng.standard_normal((batch, n)), rng.standard_normal((batch, f * r))
+    want, _ = orc.qp_build_batch(A, B, C, W3, W4, x0, ref, f, v, threads=2)
+    got = ctx.qp_build(A, B, C, f, v, W3=W3, W4=W4, x0=x0, ref=ref, interleave=1, weights_mode=ffi.WEIGHTS_DENSE)
+    for k in ("Phi", "Gamma", "H", "fvec"):
+        assert_close(got[k], want[k], f"dense W4 n{n} m{m} r{r} f{f} v{v} {k}")
+    part = ctx.qp_build(A, B, C, f, v, W3=W3, W4=W4, x0=x0, ref=ref, interleave=1, weights_mode=ffi.WEIGHTS_DENSE, want=("fvec",))
+    assert np.array_equal(part["fvec"], got["fvec"])

@@ -1,0 +1,70 @@
+"""GPU parity of the batched solve / gain (reference: controller.rs:93-96, :130-134) against the oracle and numpy.
+Tolerance: relative Frobenius error <= 1e-10 * cond(H) (a solve amplifies rounding by the condition number)."""
+import numpy as np
+import pytest
+
+from helpers import oracle_qp, random_stable_plants, rel_fro
+from mpc_rs_amd import synth
+from oracle import oracle_ffi as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,batch,il", [("two_mass", 300, 0), ("two_mass", 70, 1), ("msd", 129, 64)])
+def test_solve_and_gain_on_workloads(ctx, name, batch, il):
+    d = synth.make_batch(name, batch)
+    want = oracle_qp(orc, d)
+    u, info = ctx.qp_solve(want["H"], want["fvec"], d["m"], interleave=il)
+    assert np.all(info == 0)
+    ref_u = np.stack([-np.linalg.solve(want["H"][b], want["fvec"][b, :, 0]) for b in range(batch)])
+    cond = max(np.linalg.cond(h) for h in want["H"][:8])
+    assert rel_fro(u, ref_u) <= 1e-10 * cond
+    gain, info = ctx.qp_gain(want["H"], want["Gamma"], d["Q"], d["m"], d["r"], d["f"], d["v"], interleave=il)
+    assert np.all(info == 0)
+    w4 = synth.dense_w4(d["Q"], d["f"])
+    for b in range(0, batch, max(batch // 6, 1)):
+        st, O, M, H, G = orc.form_lifted_matrices(d["A"][b], d["B"][b], d["C"][b], d["f"], d["v"], d["W3"], w4)
+        assert st == orc.ORC_OK and rel_fro(gain[b], G) <= 1e-10 * cond
+        # first move of the reference: gain (ref - O x) == -H^-1 fvec
+        s = d["ref"][b] - O @ d["x0"][b]
+        assert abs((gain[b] @ s)[0] - u[b, 0]) <= 1e-9 * cond * max(abs(u[b, 0]), 1e-30)
+
+
+@pytest.mark.parametrize("vm,nrhs_m", [(1, 1), (2, 1), (7, 1), (20, 2), (64, 4), (65, 5), (100, 1)])
+def test_solve_shapes_and_pivoting(ctx, vm, nrhs_m):
+    rng = np.random.default_rng(vm)
+    batch = 17
+    H = rng.standard_normal((batch, vm, vm))
+    H[:, 0, 0] = 0.0  # forces a row exchange in the first step
+    fv = rng.standard_normal((batch, vm))
+    u, info = ctx.qp_solve(H, fv, 1, interleave=1)
+    if vm == 1:
+        assert np.all(info == 1) and np.all(np.isnan(u))
+        return
+    assert np.all(info == 0)
+    ref = np.stack([-np.linalg.solve(H[b], fv[b]) for b in range(batch)])
+    cond = max(np.linalg.cond(h) for h in H)
+    assert rel_fro(u, ref) <= 1e-11 * cond
+
+
+def test_singular_instances_are_flagged_not_fatal(ctx):
+    rng = np.random.default_rng(3)
+    batch, vm = 12, 6
+    H = rng.standard_normal((batch, vm, vm)) + 4 * np.eye(vm)
+    H[3] = 0.0                      # exactly singular: Err("Matrix inversion failed") in the reference
+    H[7, :, 2] = 0.0                # a zero column
+    H[9, 1, 1] = np.nan
+    fv = rng.standard_normal((batch, vm))
+    u, info = ctx.qp_solve(H, fv, 1, interleave=0)
+    assert list(np.nonzero(info)[0]) == [3, 7, 9]
+    assert np.all(np.isnan(u[[3, 7, 9]])) and np.all(np.isfinite(np.delete(u, [3, 7, 9], axis=0)))
+    good = [b for b in range(batch) if b not in (3, 7, 9)]
+    ref = np.stack([-np.linalg.solve(H[b], fv[b]) for b in good])
+    assert rel_fro(u[good], ref) <= 1e-10
+    # the all-elements weight blocks of Controller::new with repeated input columns: the reference's own failure case
+    A, C = 0.5 * np.eye(2), np.eye(2)
+    B = np.ones((2, 2))
+    qp = ctx.qp_build(A[None], B[None], C[None], 2, 2, W3=np.zeros((4, 4)), W4=np.eye(2), want=("Gamma", "H"))
+    _, info = ctx.qp_gain(qp["H"], qp["Gamma"], np.eye(2), 2, 2, 2, 2)
+    st, *_ = orc.form_lifted_matrices(A, B, C, 2, 2, np.zeros((4, 4)), np.eye(4))
+    assert info[0] == 1 and st == orc.ORC_ERR_INVERSION
