@@ -66,7 +66,8 @@ typedef struct mpcx_dims {
     int32_t v; /* control horizon, 1 <= v <= f   (controller.rs:21) */
     int32_t weights_mode; /* MPCX_WEIGHTS_* */
     int32_t hessian_algo; /* MPCX_HESSIAN_* */
-    int32_t u_shared;     /* rollout: 0 = U holds m x T per instance, 1 = one m x T shared by all instances */
+    int32_t u_shared;     /* rollout: 0 = U holds m x T per instance, 1 = one m x T shared by all instances;
+                             closed loop: the same for the reference trajectory */
     int64_t batch;        /* number of independent instances */
     int64_t T;            /* rollout: number of input columns (simulator.rs:10) */
     int64_t interleave;   /* W, see above */
@@ -143,6 +144,24 @@ int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, cons
                      double *gain, int32_t *info);
 int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *Gamma, const double *W4,
                          double *gain, int32_t *info, void *stream);
+
+/*
+ * Receding-horizon closed loop, batched: the loop of src/main.rs:51-71 for `batch` plants at once.  For t = 0 .. T-1:
+ *     s = ref[:, t .. t+f) - Phi x_t; u_t = first m entries of gain s   [compute_control_input, controller.rs:117-135]
+ *     y_t = C x_t; x_{t+1} = A x_t + B u_t                              [propagate_dynamics, controller.rs:101-115]
+ * Phi ((f r) x n) and gain ((v m) x (f r)) are per instance, as mpcx_qp_build / mpcx_qp_gain leave them.  ref is
+ * r x (T + f), time along columns: for r = 1 the reference's desired_ctrl_traj_total with time_steps = T + f
+ * (main.rs:18-24, :51); per instance, or one trajectory for the whole batch when dims->u_shared = 1.
+ * Outputs (any may be NULL): X n x (T+1) with X[:,0] = x0; U m x T; Y r x T.  The reference's `outputs` matrix
+ * (main.rs:40-41, :63) is [C x0, Y[:,0], Y[:,1], ...].  The reference handles m = r = 1 only; larger m, r follow the
+ * same formulas with the window stacked as ref[a, t+i] at row i r + a.
+ */
+int mpcx_closed_loop_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, const double *B, const double *C,
+                         const double *x0, const double *Phi, const double *gain, const double *ref, double *X, double *U,
+                         double *Y);
+int mpcx_closed_loop_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, const double *B, const double *C,
+                             const double *x0, const double *Phi, const double *gain, const double *ref, double *X,
+                             double *U, double *Y, void *stream);
 
 /*
  * Reduces `count` f64 values at device pointer `buf` to one mpcx_stats record written to device memory

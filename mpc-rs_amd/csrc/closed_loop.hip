@@ -1,0 +1,333 @@
+// Batched receding-horizon closed loop: for t = 0 .. T-1
+//     s   = ref[t .. t+f) - Phi x_t                  (controller.rs:119-127)
+//     u_t = first m entries of gain s                (controller.rs:130-132; the reference is m = r = 1)
+//     y_t = C x_t,  x_{t+1} = A x_t + B u_t          (controller.rs:101-115)
+// which is the loop of src/main.rs:51-71 run for `batch` plants at once.  Phi and gain are the per-instance outputs of
+// the QP build and of the gain solve; only the first m rows of the gain are read.
+//
+// The reference trajectory is r x (T + f), time along columns (for r = 1 this is the reference's T_total x 1
+// desired_ctrl_traj_total with time_steps = T + f, main.rs:18-24); step t uses columns t .. t+f-1.
+//
+// Time is serial, parallelism comes from the batch.  Two kernels, as for the open-loop rollout:
+//   closed_loop_lane   tiny plants: one lane per instance; A, B, C, x in registers; Phi and the first gain rows in a
+//                      per-lane LDS column (no barriers: a lane only ever touches its own column).
+//   closed_loop_group  any n, m, r <= 64: one wavefront per instance, everything in LDS.
+// Loads and stores of a wave retire through one in-order counter, so a load issued after a store cannot be consumed
+// before that store has reached memory.  Both kernels therefore fetch the per-instance reference a chunk of kChunk
+// steps ahead: the wait for a chunk's loads only covers stores that are a whole chunk old.  A reference shared by the
+// batch is read through the scalar cache and needs none of this.
+#include "mpcx_internal.h"
+
+namespace mpcx {
+bool qp_lane_supports(int n, int m, int r);
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kChunk = 8;
+
+template <int N, int M, int R, bool SHARED>
+__global__ __launch_bounds__(kWave) void closed_loop_lane_kernel(LoopArgs p, const double *__restrict__ ref_shared) {
+    extern __shared__ double lds[];
+    const int ln = threadIdx.x;
+    const long long b = (long long)blockIdx.x * kWave + ln;
+    if (b >= p.batch) return;
+    const long long W = p.W, tile = b / W, lane = b - tile * W, T = p.T;
+    const int F = p.f, FR = F * R, VM = p.v * M;
+#define IN(ptr, E, e) ((ptr)[tile * (long long)(E) * W + (long long)(e) * W + lane])
+    double *sPhi = lds + ln;                        // element e at sPhi[e * 64]
+    double *sK = sPhi + (size_t)FR * N * kWave;     // (c, k) at sK[(c * M + k) * 64]
+    double *sRing = sK + (size_t)FR * M * kWave;    // column tau, row a at sRing[((tau % RC) * R + a) * 64]
+    const int RC = F + kChunk;
+    const long long L = T + F, ER = (long long)R * L;
+
+    double A[N][N], Bm[N][M], Cm[R][N], x[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) A[i][j] = IN(p.A, N * N, j * N + i);
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) Bm[i][j] = IN(p.B, N * M, j * N + i);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < R; ++i) Cm[i][j] = IN(p.C, R * N, j * R + i);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = IN(p.x0, N, i);
+    for (int e = 0; e < FR * N; ++e) sPhi[e * kWave] = IN(p.Phi, FR * N, e);
+    for (int c = 0; c < FR; ++c)
+#pragma unroll
+        for (int k = 0; k < M; ++k) sK[(c * M + k) * kWave] = IN(p.gain, (long long)VM * FR, (long long)c * VM + k);
+
+    double pre[kChunk][R];
+    if (!SHARED) {
+        const long long first = (kChunk + F - 1 < L) ? kChunk + F - 1 : L;
+        for (long long tau = 0; tau < first; ++tau)
+#pragma unroll
+            for (int a = 0; a < R; ++a) sRing[((int)(tau % RC) * R + a) * kWave] = IN(p.ref, ER, tau * R + a);
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const long long tau = kChunk + F - 1 + q;
+#pragma unroll
+            for (int a = 0; a < R; ++a) pre[q][a] = (tau < L) ? IN(p.ref, ER, tau * R + a) : 0.0;
+        }
+    }
+
+    const long long EX = (long long)N * (T + 1), EY = (long long)R * T, EU = (long long)M * T;
+    if (p.X) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) IN(p.X, EX, i) = x[i];
+    }
+    for (long long t = 0; t < T; ++t) {
+        if (!SHARED && t > 0 && (t % kChunk) == 0) {
+            // columns [t + F - 1, t + F - 1 + kChunk) arrive from the registers filled one chunk ago; the next chunk's
+            // loads go out before this chunk's stores
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                const long long tau = t + F - 1 + q;
+#pragma unroll
+                for (int a = 0; a < R; ++a) sRing[((int)(tau % RC) * R + a) * kWave] = pre[q][a];
+            }
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                const long long tau = t + kChunk + F - 1 + q;
+#pragma unroll
+                for (int a = 0; a < R; ++a) pre[q][a] = (tau < L) ? IN(p.ref, ER, tau * R + a) : 0.0;
+            }
+        }
+        double u[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) u[k] = 0.0;
+        int slot = (int)(t % RC);
+        for (int i = 0; i < F; ++i) {
+#pragma unroll
+            for (int a = 0; a < R; ++a) {
+                const int c = i * R + a;
+                double ox = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) ox += sPhi[(j * FR + c) * kWave] * x[j];
+                const double rv = SHARED ? ref_shared[(t + i) * R + a] : sRing[(slot * R + a) * kWave];
+                const double s = rv - ox;
+#pragma unroll
+                for (int k = 0; k < M; ++k) u[k] += sK[(c * M + k) * kWave] * s;
+            }
+            slot = (slot + 1 == RC) ? 0 : slot + 1;
+        }
+        if (p.U) {
+#pragma unroll
+            for (int k = 0; k < M; ++k) IN(p.U, EU, t * M + k) = u[k];
+        }
+        if (p.Y) {
+#pragma unroll
+            for (int a = 0; a < R; ++a) {
+                double y = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) y += Cm[a][j] * x[j];
+                IN(p.Y, EY, t * R + a) = y;
+            }
+        }
+        double xn[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) s += A[i][j] * x[j];
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) q += Bm[i][k] * u[k];
+            xn[i] = s + q;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = xn[i];
+        if (p.X) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) IN(p.X, EX, (t + 1) * N + i) = x[i];
+        }
+    }
+#undef IN
+}
+
+size_t lane_lds_bytes(int n, int m, int r, int f, bool shared) {
+    const size_t per_lane = (size_t)f * r * (n + m) + (shared ? 0 : (size_t)(f + kChunk) * r);
+    return per_lane * kWave * sizeof(double);
+}
+
+template <int N, int M, int R>
+int launch_lane_one(const LoopArgs &a, hipStream_t s) {
+    const long long blocks = (a.batch + kWave - 1) / kWave;
+    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    const size_t lds_bytes = lane_lds_bytes(N, M, R, a.f, a.ref_shared != 0);
+    const void *fn = a.ref_shared ? (const void *)closed_loop_lane_kernel<N, M, R, true>
+                                  : (const void *)closed_loop_lane_kernel<N, M, R, false>;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (a.ref_shared)
+        hipLaunchKernelGGL((closed_loop_lane_kernel<N, M, R, true>), dim3((unsigned)blocks), dim3(kWave), lds_bytes, s, a, a.ref);
+    else
+        hipLaunchKernelGGL((closed_loop_lane_kernel<N, M, R, false>), dim3((unsigned)blocks), dim3(kWave), lds_bytes, s, a, a.ref);
+    return (int)hipGetLastError();
+}
+
+// One wavefront per instance.  LDS: A, B, C, Phi, first m gain rows, two state buffers, s, u, the reference ring
+// and a staging area holding kChunk steps of outputs, flushed in one burst per chunk.
+__global__ __launch_bounds__(kWave) void closed_loop_group_kernel(LoopArgs p, const double *__restrict__ ref_shared) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long long b = blockIdx.x;
+    const int n = p.n, m = p.m, r = p.r, F = p.f, FR = F * r, VM = p.v * m;
+    const long long W = p.W, tile = b / W, li = b - tile * W, T = p.T;
+    const long long L = T + F, ER = (long long)r * L;
+    const int RC = F + kChunk;
+    const bool shared = p.ref_shared != 0;
+#define IN(ptr, E, e) ((ptr)[tile * (long long)(E) * W + (long long)(e) * W + li])
+    double *sA = lds, *sB = sA + n * n, *sC = sB + n * m, *sPhi = sC + r * n, *sK = sPhi + (size_t)FR * n;
+    double *sx = sK + (size_t)FR * m, *ss = sx + 2 * n, *su = ss + FR, *sOut = su + m;
+    const int out_per_step = n + m + r;
+    double *sRing = sOut + kChunk * out_per_step;  // (tau % RC) * r + a
+    for (int e = lane; e < n * n; e += kWave) sA[e] = IN(p.A, n * n, e);
+    for (int e = lane; e < n * m; e += kWave) sB[e] = IN(p.B, n * m, e);
+    for (int e = lane; e < r * n; e += kWave) sC[e] = IN(p.C, r * n, e);
+    for (int e = lane; e < FR * n; e += kWave) sPhi[e] = IN(p.Phi, (long long)FR * n, e);
+    for (int e = lane; e < FR * m; e += kWave) {  // sK[c * m + k] = gain(k, c)
+        const int c = e / m, k = e - c * m;
+        sK[e] = IN(p.gain, (long long)VM * FR, (long long)c * VM + k);
+    }
+    const long long EX = (long long)n * (T + 1), EY = (long long)r * T, EU = (long long)m * T;
+    if (lane < n) {
+        const double x0 = IN(p.x0, n, lane);
+        sx[lane] = x0;
+        if (p.X) IN(p.X, EX, lane) = x0;
+    }
+    // reference ring: columns [0, kChunk + F - 1) now; later chunks are fetched one chunk ahead into `pre`
+    // (lane q of the first kChunk * r lanes... r <= 64 and kChunk * r may exceed 64, so each lane keeps kChunk slots)
+    double pre[kChunk];
+    if (!shared) {
+        const long long first = (kChunk + F - 1 < L) ? kChunk + F - 1 : L;
+        for (long long e = lane; e < first * r; e += kWave) sRing[(int)((e / r) % RC) * r + (int)(e % r)] = IN(p.ref, ER, e);
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            const long long tau = kChunk + F - 1 + q;
+            pre[q] = (lane < r && tau < L) ? IN(p.ref, ER, tau * r + lane) : 0.0;
+        }
+    }
+    lds_barrier();
+    for (long long t0 = 0; t0 < T; t0 += kChunk) {
+        const int steps = (int)((T - t0 < kChunk) ? T - t0 : kChunk);
+        if (!shared && t0 > 0) {
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                const long long tau = t0 + F - 1 + q;
+                if (lane < r) sRing[(int)(tau % RC) * r + lane] = pre[q];
+            }
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                const long long tau = t0 + kChunk + F - 1 + q;
+                pre[q] = (lane < r && tau < L) ? IN(p.ref, ER, tau * r + lane) : 0.0;
+            }
+            lds_barrier();
+        }
+        for (int q = 0; q < steps; ++q) {
+            const long long t = t0 + q;
+            const double *xc = sx + (t & 1) * n;
+            double *xn = sx + ((t + 1) & 1) * n;
+            double *out = sOut + q * out_per_step;  // [x_{t+1} (n) | u_t (m) | y_t (r)]
+            // s = ref window - Phi x, lanes along the rows of s; partial sums of u = K s stay in the lane
+            double uacc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int c = lane; c < FR; c += kWave) {
+                double ox = 0.0;
+                for (int j = 0; j < n; ++j) ox += sPhi[j * FR + c] * xc[j];
+                const int i = c / r, a = c - i * r;
+                const double rv = shared ? ref_shared[(t + i) * r + a] : sRing[(int)((t + i) % RC) * r + a];
+                const double s = rv - ox;
+                if (m <= 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) uacc[k] += sK[c * m + (k < m ? k : 0)] * (k < m ? s : 0.0);
+                } else {
+                    ss[c] = s;
+                }
+            }
+            if (m <= 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double v = uacc[k];
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                    if (lane == 0 && k < m) { su[k] = v; out[n + k] = v; }
+                }
+            } else {
+                lds_barrier();
+                if (lane < m) {
+                    double v = 0.0;
+                    for (int c = 0; c < FR; ++c) v += sK[c * m + lane] * ss[c];
+                    su[lane] = v;
+                    out[n + lane] = v;
+                }
+            }
+            lds_barrier();
+            if (lane < n) {
+                double s = 0.0;
+                for (int j = 0; j < n; ++j) s += sA[j * n + lane] * xc[j];
+                double qv = 0.0;
+                for (int k = 0; k < m; ++k) qv += sB[k * n + lane] * su[k];
+                s += qv;
+                xn[lane] = s;
+                out[lane] = s;
+            }
+            if (lane < r) {
+                double y = 0.0;
+                for (int j = 0; j < n; ++j) y += sC[j * r + lane] * xc[j];
+                out[n + m + lane] = y;
+            }
+            lds_barrier();
+        }
+        // flush the chunk: X columns t0+1 .. t0+steps are contiguous per instance, likewise U and Y
+        if (p.X)
+            for (int e = lane; e < steps * n; e += kWave) IN(p.X, EX, (t0 + 1) * n + e) = sOut[(e / n) * out_per_step + (e % n)];
+        if (p.U)
+            for (int e = lane; e < steps * m; e += kWave) IN(p.U, EU, t0 * m + e) = sOut[(e / m) * out_per_step + n + (e % m)];
+        if (p.Y)
+            for (int e = lane; e < steps * r; e += kWave) IN(p.Y, EY, t0 * r + e) = sOut[(e / r) * out_per_step + n + m + (e % r)];
+        lds_barrier();
+    }
+#undef IN
+}
+
+size_t group_lds_bytes(const LoopArgs &a) {
+    const size_t fr = (size_t)a.f * a.r;
+    size_t d = (size_t)a.n * a.n + (size_t)a.n * a.m + (size_t)a.r * a.n + fr * a.n + fr * a.m + 2 * a.n + fr + a.m +
+               (size_t)kChunk * (a.n + a.m + a.r);
+    if (!a.ref_shared) d += (size_t)(a.f + kChunk) * a.r;
+    return d * sizeof(double);
+}
+
+}  // namespace
+
+int launch_closed_loop_lane(const LoopArgs &a, hipStream_t s) {
+    if (!qp_lane_supports(a.n, a.m, a.r)) return MPCX_ERR_UNSUPPORTED;
+    if (lane_lds_bytes(a.n, a.m, a.r, a.f, a.ref_shared != 0) > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
+#define CASE(N_, M_, R_) \
+    if (a.n == N_ && a.m == M_ && a.r == R_) return launch_lane_one<N_, M_, R_>(a, s);
+    CASE(1, 1, 1) CASE(2, 1, 1) CASE(3, 1, 1) CASE(4, 1, 1) CASE(5, 1, 1) CASE(6, 1, 1)
+    CASE(2, 2, 2) CASE(4, 2, 2) CASE(6, 2, 2)
+    CASE(3, 2, 1) CASE(4, 2, 1) CASE(3, 1, 2) CASE(4, 1, 2)
+#undef CASE
+    return MPCX_ERR_UNSUPPORTED;
+}
+
+int launch_closed_loop_group(const LoopArgs &a, hipStream_t s) {
+    if (a.n > kWave || a.m > kWave || a.r > kWave) return MPCX_ERR_UNSUPPORTED;
+    if (a.batch > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    const size_t lds_bytes = group_lds_bytes(a);
+    if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)closed_loop_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(closed_loop_group_kernel, dim3((unsigned)a.batch), dim3(kWave), lds_bytes, s, a, a.ref);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mpcx

@@ -430,6 +430,75 @@ int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const d
     return MPCX_OK;
 }
 
+int mpcx_closed_loop_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,
+                             const double *x0, const double *Phi, const double *gain, const double *ref, double *X,
+                             double *U, double *Y, void *stream) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->T < 0) return fail(ctx, MPCX_ERR_DIMS, "T must be >= 0");
+    if (d->f < 1 || d->v < 1 || d->v > d->f) return fail(ctx, MPCX_ERR_DIMS, "need f >= 1 and 1 <= v <= f");
+    if (d->batch == 0) return MPCX_OK;
+    if (!A || !B || !C || !x0 || !Phi || !gain || !ref) return fail(ctx, MPCX_ERR_NULL, "A, B, C, x0, Phi, gain and ref are required");
+    if (!X && !U && !Y) return MPCX_OK;
+    LoopArgs a;
+    a.A = A; a.B = B; a.C = C; a.x0 = x0; a.Phi = Phi; a.gain = gain; a.ref = ref; a.X = X; a.U = U; a.Y = Y;
+    a.batch = d->batch; a.W = W; a.T = d->T;
+    a.n = d->n; a.m = d->m; a.r = d->r; a.f = d->f; a.v = d->v; a.ref_shared = d->u_shared;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = (W == 1) ? MPCX_ERR_UNSUPPORTED : launch_closed_loop_lane(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED) rc = launch_closed_loop_group(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED && W == 1) rc = launch_closed_loop_lane(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED)
+        return fail(ctx, rc, "closed loop: n=%d m=%d r=%d f=%d does not fit on chip", d->n, d->m, d->r, d->f);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "closed loop launch");
+    return MPCX_OK;
+}
+
+int mpcx_closed_loop_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,
+                         const double *x0, const double *Phi, const double *gain, const double *ref, double *X, double *U,
+                         double *Y) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->T < 0) return fail(ctx, MPCX_ERR_DIMS, "T must be >= 0");
+    if (d->batch == 0) return MPCX_OK;
+    if (!A || !B || !C || !x0 || !Phi || !gain || !ref) return fail(ctx, MPCX_ERR_NULL, "A, B, C, x0, Phi, gain and ref are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long n = d->n, m = d->m, r = d->r, f = d->f, v = d->v, bt = d->batch, il = d->interleave, T = d->T;
+    constexpr int NI = 7, NO = 3;
+    const double *hin[NI] = {A, B, C, x0, Phi, gain, ref};
+    const long long nin[NI] = {mpcx_array_elems(bt, il, n * n), mpcx_array_elems(bt, il, n * m), mpcx_array_elems(bt, il, r * n),
+                               mpcx_array_elems(bt, il, n), mpcx_array_elems(bt, il, f * r * n),
+                               mpcx_array_elems(bt, il, v * m * f * r),
+                               d->u_shared ? r * (T + f) : mpcx_array_elems(bt, il, r * (T + f))};
+    double *hout[NO] = {X, U, Y};
+    const long long nout[NO] = {mpcx_array_elems(bt, il, n * (T + 1)), mpcx_array_elems(bt, il, m * T), mpcx_array_elems(bt, il, r * T)};
+    size_t off_in[NI], off_out[NO], total = 0;
+    for (int i = 0; i < NI; ++i) { off_in[i] = total; total += align256((size_t)nin[i] * sizeof(double)); }
+    for (int i = 0; i < NO; ++i) { off_out[i] = total; if (hout[i]) total += align256((size_t)nout[i] * sizeof(double)); }
+    rc = ensure_work(ctx, total ? total : 256);
+    if (rc != MPCX_OK) return rc;
+    char *base = (char *)ctx->work;
+    const double *din[NI];
+    double *dout[NO];
+    for (int i = 0; i < NI; ++i) {
+        din[i] = (const double *)(base + off_in[i]);
+        if (nin[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync((void *)din[i], hin[i], (size_t)nin[i] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (int i = 0; i < NO; ++i) dout[i] = hout[i] ? (double *)(base + off_out[i]) : nullptr;
+    rc = mpcx_closed_loop_f64_dev(ctx, d, din[0], din[1], din[2], din[3], din[4], din[5], din[6], dout[0], dout[1], dout[2],
+                                  (void *)ctx->stream);
+    if (rc != MPCX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    for (int i = 0; i < NO; ++i)
+        if (hout[i] && nout[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(hout[i], dout[i], (size_t)nout[i] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCX_OK;
+}
+
 int mpcx_stats_f64_dev(mpcx_ctx *ctx, const double *buf, int64_t count, mpcx_stats *out_dev, void *stream) {
     if (!ctx) return MPCX_ERR_NULL;
     if (!out_dev || (count > 0 && !buf)) return fail(ctx, MPCX_ERR_NULL, "buf / out_dev is NULL");

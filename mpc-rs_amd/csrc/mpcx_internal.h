@@ -26,6 +26,15 @@ struct RolloutArgs {
     int u_shared;
 };
 
+// Receding-horizon closed loop: Phi (f r x n) and gain (v m x f r) per instance, ref r x (T + f) per instance or shared.
+struct LoopArgs {
+    const double *A, *B, *C, *x0, *Phi, *gain, *ref;
+    double *X, *U, *Y;
+    long long batch, W, T;
+    int n, m, r, f, v;
+    int ref_shared;
+};
+
 // Each launcher returns hipSuccess / a hipError_t, or MPCX_ERR_UNSUPPORTED when the dimensions are outside
 // what that kernel family holds on chip (the caller then tries the next family).
 int launch_qp_lane(const QpArgs &a, hipStream_t s);
@@ -36,6 +45,8 @@ int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *inf
                     hipStream_t s);
 int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double *gain, int *info, long long batch,
                    long long W, int m, int r, int f, int v, hipStream_t s);
+int launch_closed_loop_lane(const LoopArgs &a, hipStream_t s);
+int launch_closed_loop_group(const LoopArgs &a, hipStream_t s);
 int launch_rollout_lane(const RolloutArgs &a, hipStream_t s);
 int launch_rollout_group(const RolloutArgs &a, hipStream_t s);
 int launch_stats(const double *buf, long long count, mpcx_stats *out_dev, void *scratch, size_t scratch_bytes,

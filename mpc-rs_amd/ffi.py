@@ -26,6 +26,7 @@ EXPORTS = (
     "mpcx_version", "mpcx_array_elems", "mpcx_create", "mpcx_destroy", "mpcx_last_error",
     "mpcx_qp_build_f64", "mpcx_qp_build_f64_dev", "mpcx_rollout_f64", "mpcx_rollout_f64_dev",
     "mpcx_qp_solve_f64", "mpcx_qp_solve_f64_dev", "mpcx_qp_gain_f64", "mpcx_qp_gain_f64_dev",
+    "mpcx_closed_loop_f64", "mpcx_closed_loop_f64_dev",
     "mpcx_stats_f64_dev", "mpcx_stats_f64", "mpcx_relayout_f64_dev",
 )
 
@@ -93,6 +94,10 @@ def lib() -> C.CDLL:
     lb.mpcx_qp_gain_f64.restype = C.c_int
     lb.mpcx_qp_gain_f64_dev.argtypes = [vp, C.POINTER(Dims), dp, dp, dp, dp, vp, vp]
     lb.mpcx_qp_gain_f64_dev.restype = C.c_int
+    lb.mpcx_closed_loop_f64.argtypes = [vp, C.POINTER(Dims)] + [dp] * 10
+    lb.mpcx_closed_loop_f64.restype = C.c_int
+    lb.mpcx_closed_loop_f64_dev.argtypes = [vp, C.POINTER(Dims)] + [dp] * 10 + [vp]
+    lb.mpcx_closed_loop_f64_dev.restype = C.c_int
     lb.mpcx_stats_f64_dev.argtypes = [vp, dp, i64, vp, vp]
     lb.mpcx_stats_f64_dev.restype = C.c_int
     lb.mpcx_stats_f64.argtypes = [vp, dp, i64, C.POINTER(Stats)]
@@ -222,6 +227,31 @@ class Context:
         info = np.full(max(batch, 1), -1, dtype=np.int32)
         self._check(self._lib.mpcx_qp_gain_f64(self._h, C.byref(d), _hp(hb), _hp(gb), _hp(qb), _hp(out), info.ctypes.data_as(C.c_void_p)))
         return L.unpack(out, batch, v * m, f * r, interleave), info[:batch]
+
+    def closed_loop_dev(self, dims: Dims, A, B, Cm, x0, Phi, gain, ref, X, U, Y, stream=0):
+        self._check(self._lib.mpcx_closed_loop_f64_dev(self._h, C.byref(dims), A, B, Cm, x0, Phi, gain, ref, X, U, Y, stream))
+
+    def closed_loop(self, A, B, Cm, x0, Phi, gain, ref, T, f, v, interleave=L.INTERLEAVE_AOS, want=("X", "U", "Y")):
+        """Receding-horizon loop for a batch.  ref: (r, T+f) shared by the batch, or (batch, r, T+f) per instance.
+        Returns X (batch, n, T+1), U (batch, m, T), Y (batch, r, T)."""
+        A = np.asarray(A, dtype=np.float64)
+        B = np.asarray(B, dtype=np.float64)
+        Cm = np.asarray(Cm, dtype=np.float64)
+        ref = np.asarray(ref, dtype=np.float64)
+        batch, n, m, r = A.shape[0], A.shape[1], B.shape[2], Cm.shape[1]
+        shared = ref.ndim == 2
+        assert ref.shape[-2:] == (r, T + f), "ref must be r x (T + f)"
+        d = make_dims(n, m, r, f, v, batch, T, interleave, u_shared=1 if shared else 0)
+        ins = [L.pack(A, interleave), L.pack(B, interleave), L.pack(Cm, interleave),
+               L.pack(np.asarray(x0, dtype=np.float64).reshape(batch, n, 1), interleave),
+               L.pack(np.asarray(Phi, dtype=np.float64), interleave), L.pack(np.asarray(gain, dtype=np.float64), interleave),
+               L.colmajor(ref) if shared else L.pack(ref, interleave)]
+        shapes = {"X": (n, T + 1), "U": (m, T), "Y": (r, T)}
+        outs = {k: (np.full(max(L.array_elems(batch, interleave, rr * cc), 1), np.nan) if k in want else None)
+                for k, (rr, cc) in shapes.items()}
+        self._check(self._lib.mpcx_closed_loop_f64(self._h, C.byref(d), *[_hp(a) for a in ins],
+                                                   _hp(outs["X"]), _hp(outs["U"]), _hp(outs["Y"])))
+        return {k: L.unpack(outs[k], batch, *shapes[k], interleave) for k in want}
 
     def rollout(self, A, B, Cm, x0, U, interleave=L.INTERLEAVE_AOS, want=("X", "Y")):
         """U is (batch, m, T) or, shared by all instances, (m, T).  Returns X (batch, n, T+1), Y (batch, r, T)."""
