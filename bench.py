@@ -2,11 +2,12 @@
 """Benchmark of the batched MPC hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload two_mass|msd|quadrotor|long]
-                    [--op qp|rollout] [--batch B_per_gpu] [--interleave W]
+                    [--op qp|rollout|solve|gain|loop] [--batch B_per_gpu] [--interleave W]
 
 One "step" = one pass of the hot path over the rank's resident shard of synthetic plants: for --op qp one call of
 mpcx_qp_build_f64_dev storing Phi, Gamma, H and fvec for every instance; for --op rollout one call of
-mpcx_rollout_f64_dev storing X and Y.  Inputs and outputs live in HBM before the timed region starts.  Instances
+mpcx_rollout_f64_dev storing X and Y; --op solve / gain / loop time the batched solve u = -H^-1 f, the gain
+H^-1 Gamma^T W4 and the receding-horizon closed loop (X, U, Y stored) on operands a device-side build left in HBM.  Inputs and outputs live in HBM before the timed region starts.  Instances
 are sharded by index across ranks (one process per GPU, no collective on the data path, "weak" scaling: the
 per-GPU batch is fixed); after the timed region the ranks all-gather one fixed-size statistics record each over
 RCCL.  Rank 0 prints ONE JSON line.
@@ -41,6 +42,19 @@ def bytes_rollout(n, m, r, T):
     return 8 * (n * n + n * m + r * n + n + m * T + n * (T + 1) + r * T)
 
 
+def bytes_solve(m, v):
+    return 8 * ((v * m) ** 2 + 2 * v * m) + 4
+
+
+def bytes_gain(m, r, f, v):
+    return 8 * ((v * m) ** 2 + 2 * f * r * v * m) + 4
+
+
+def bytes_loop(n, m, r, f, T):
+    # A, B, C, x0, Phi, the first m rows of the gain; X, U, Y stored; the reference trajectory is shared
+    return 8 * (n * n + n * m + r * n + n + f * r * n + m * f * r + n * (T + 1) + m * T + r * T)
+
+
 def flops_h(m, r, f, v):
     return (f * r) * (v * m) * (v * m + 1) + 2 * f * r * r * v * m
 
@@ -51,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="two_mass", choices=sorted(DEFAULT_BATCH))
-    ap.add_argument("--op", default="qp", choices=["qp", "rollout"])
+    ap.add_argument("--op", default="qp", choices=["qp", "rollout", "solve", "gain", "loop"])
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's own)")
     ap.add_argument("--interleave", type=int, default=-1, help="-1: layout the kernels are native in")
     ap.add_argument("--hessian", type=int, default=0, help="0 auto, 1 dense contraction, 2 structured")
@@ -111,6 +125,49 @@ def main():
         unit_bytes = bytes_qp(n, m, r, f, v)
         metric, unit = "batched MPC QP builds/sec (Phi,Gamma,H,f)", "builds/s"
         check_buf = outs["H"]
+    elif args.op in ("solve", "gain", "loop"):
+        # operands come from a device-side build (and gain solve) outside the timed region
+        qp = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
+        dims = ffi.make_dims(n, m, r, f, v, count, T, il, u_shared=1)
+        ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["W3"].data_ptr(),
+                         bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(), qp["Phi"].data_ptr(),
+                         qp["Gamma"].data_ptr(), qp["H"].data_ptr(), qp["fvec"].data_ptr(), sp)
+        info = torch.zeros(count, dtype=torch.int32, device=dev)
+        if args.op == "solve":
+            outs = {"u_seq": out(v * m)}
+
+            def step():
+                ctx.qp_solve_dev(dims, qp["H"].data_ptr(), qp["fvec"].data_ptr(), outs["u_seq"].data_ptr(), info.data_ptr(), sp)
+            unit_bytes = bytes_solve(m, v)
+            metric, unit = "batched condensed-QP solves/sec (u = -H^-1 f)", "solves/s"
+            check_buf = outs["u_seq"]
+        else:
+            outs = {"gain": out(v * m * f * r)}
+
+            def gain_step():
+                ctx.qp_gain_dev(dims, qp["H"].data_ptr(), qp["Gamma"].data_ptr(), bufs["Q"].data_ptr(),
+                                outs["gain"].data_ptr(), info.data_ptr(), sp)
+            if args.op == "gain":
+                step = gain_step
+                unit_bytes = bytes_gain(m, r, f, v)
+                metric, unit = "batched MPC gain matrices/sec (H^-1 Gamma^T W4)", "gains/s"
+                check_buf = outs["gain"]
+            else:
+                gain_step()
+                pulse = np.zeros((r, T + f))
+                pulse[:, : (T + f) // 3] = 1.0
+                pulse[:, 2 * (T + f) // 3:] = 1.0          # the shape of trajectory.rs:4-8
+                bufs["traj"] = to_dev(L.colmajor(pulse))
+                outs.update({"X": out(n * (T + 1)), "U": out(m * T), "Y": out(r * T)})
+
+                def step():
+                    ctx.closed_loop_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(),
+                                        bufs["x0"].data_ptr(), qp["Phi"].data_ptr(), outs["gain"].data_ptr(),
+                                        bufs["traj"].data_ptr(), outs["X"].data_ptr(), outs["U"].data_ptr(),
+                                        outs["Y"].data_ptr(), sp)
+                unit_bytes = bytes_loop(n, m, r, f, T)
+                metric, unit = "batched MPC closed-loop trajectories/sec (X,U,Y)", "trajectories/s"
+                check_buf = outs["X"]
     else:
         outs = {"X": out(n * (T + 1)), "Y": out(r * T)}
         dims = ffi.make_dims(n, m, r, 1, 1, count, T, il, u_shared=1)
@@ -180,7 +237,7 @@ def main():
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: n={n} m={m} r={r} f=v={f}" + (f" T={T}" if args.op == "rollout" else ""),
+            "config": {"workload": f"{args.workload}: n={n} m={m} r={r} f=v={f}" + (f" T={T}" if args.op in ("rollout", "loop") else ""),
                        "op": args.op, "batch_per_gpu": per_gpu, "global_batch": total, "interleave": il,
                        "parallelism": f"batch-sharded x{world}", "hessian_algo": args.hessian},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -198,7 +255,9 @@ def main():
                                "kernel": "hessian_mfma_kernel", "flops_per_unit": flops_h(m, r, f, v),
                                "dense_flops_per_unit": 2 * f * r * (v * m) ** 2, "step_ms_all_kernels": kernel_ms,
                                "hbm_frac_whole_step": achieved / HBM_PEAK}
-        if world == 1 and not args.no_cpu_baseline:
+        if args.op in ("solve", "gain", "loop"):
+            res["check"]["singular_instances"] = int((info != 0).sum().item())
+        if world == 1 and not args.no_cpu_baseline and args.op in ("qp", "rollout"):
             res["cpu_baseline"] = _cpu_baseline(args, d, n, m, r, f, v, T, unit)
         print(json.dumps(res), flush=True)
     ctx.close()

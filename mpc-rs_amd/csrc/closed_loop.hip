@@ -25,18 +25,22 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kChunk = 8;
 
-template <int N, int M, int R, bool SHARED>
+// FS > 0: the horizon is the compile-time constant FS and Phi and the gain rows live in registers (no LDS traffic in
+// the loop); FS = 0: any horizon, Phi and the gain rows in the lane's LDS column.
+template <int N, int M, int R, bool SHARED, int FS>
 __global__ __launch_bounds__(kWave) void closed_loop_lane_kernel(LoopArgs p, const double *__restrict__ ref_shared) {
     extern __shared__ double lds[];
     const int ln = threadIdx.x;
     const long long b = (long long)blockIdx.x * kWave + ln;
     if (b >= p.batch) return;
     const long long W = p.W, tile = b / W, lane = b - tile * W, T = p.T;
-    const int F = p.f, FR = F * R, VM = p.v * M;
+    const int F = FS > 0 ? FS : p.f, FR = F * R, VM = p.v * M;
+    constexpr int kRegs = FS > 0 ? FS * R : 1;
+    double rPhi[kRegs][N], rK[kRegs][M];
 #define IN(ptr, E, e) ((ptr)[tile * (long long)(E) * W + (long long)(e) * W + lane])
-    double *sPhi = lds + ln;                        // element e at sPhi[e * 64]
-    double *sK = sPhi + (size_t)FR * N * kWave;     // (c, k) at sK[(c * M + k) * 64]
-    double *sRing = sK + (size_t)FR * M * kWave;    // column tau, row a at sRing[((tau % RC) * R + a) * 64]
+    double *sPhi = lds + ln;                                       // element e at sPhi[e * 64]
+    double *sK = sPhi + (FS > 0 ? 0 : (size_t)FR * N * kWave);     // (c, k) at sK[(c * M + k) * 64]
+    double *sRing = sK + (FS > 0 ? 0 : (size_t)FR * M * kWave);    // column tau, row a at sRing[((tau % RC) * R + a) * 64]
     const int RC = F + kChunk;
     const long long L = T + F, ER = (long long)R * L;
 
@@ -55,10 +59,21 @@ __global__ __launch_bounds__(kWave) void closed_loop_lane_kernel(LoopArgs p, con
         for (int i = 0; i < R; ++i) Cm[i][j] = IN(p.C, R * N, j * R + i);
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = IN(p.x0, N, i);
-    for (int e = 0; e < FR * N; ++e) sPhi[e * kWave] = IN(p.Phi, FR * N, e);
-    for (int c = 0; c < FR; ++c)
+    if constexpr (FS > 0) {
 #pragma unroll
-        for (int k = 0; k < M; ++k) sK[(c * M + k) * kWave] = IN(p.gain, (long long)VM * FR, (long long)c * VM + k);
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int c = 0; c < kRegs; ++c) rPhi[c][j] = IN(p.Phi, kRegs * N, j * kRegs + c);
+#pragma unroll
+        for (int c = 0; c < kRegs; ++c)
+#pragma unroll
+            for (int k = 0; k < M; ++k) rK[c][k] = IN(p.gain, (long long)VM * kRegs, (long long)c * VM + k);
+    } else {
+        for (int e = 0; e < FR * N; ++e) sPhi[e * kWave] = IN(p.Phi, FR * N, e);
+        for (int c = 0; c < FR; ++c)
+#pragma unroll
+            for (int k = 0; k < M; ++k) sK[(c * M + k) * kWave] = IN(p.gain, (long long)VM * FR, (long long)c * VM + k);
+    }
 
     double pre[kChunk][R];
     if (!SHARED) {
@@ -100,19 +115,38 @@ __global__ __launch_bounds__(kWave) void closed_loop_lane_kernel(LoopArgs p, con
 #pragma unroll
         for (int k = 0; k < M; ++k) u[k] = 0.0;
         int slot = (int)(t % RC);
-        for (int i = 0; i < F; ++i) {
+        if constexpr (FS > 0) {
 #pragma unroll
-            for (int a = 0; a < R; ++a) {
-                const int c = i * R + a;
-                double ox = 0.0;
+            for (int i = 0; i < FS; ++i) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) ox += sPhi[(j * FR + c) * kWave] * x[j];
-                const double rv = SHARED ? ref_shared[(t + i) * R + a] : sRing[(slot * R + a) * kWave];
-                const double s = rv - ox;
+                for (int a = 0; a < R; ++a) {
+                    const int c = i * R + a;
+                    double ox = 0.0;
 #pragma unroll
-                for (int k = 0; k < M; ++k) u[k] += sK[(c * M + k) * kWave] * s;
+                    for (int j = 0; j < N; ++j) ox += rPhi[c][j] * x[j];
+                    const double rv = SHARED ? ref_shared[(t + i) * R + a] : sRing[(slot * R + a) * kWave];
+                    const double s = rv - ox;
+#pragma unroll
+                    for (int k = 0; k < M; ++k) u[k] += rK[c][k] * s;
+                }
+                slot = (slot + 1 == RC) ? 0 : slot + 1;
             }
-            slot = (slot + 1 == RC) ? 0 : slot + 1;
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < F; ++i) {
+#pragma unroll
+                for (int a = 0; a < R; ++a) {
+                    const int c = i * R + a;
+                    double ox = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) ox += sPhi[(j * FR + c) * kWave] * x[j];
+                    const double rv = SHARED ? ref_shared[(t + i) * R + a] : sRing[(slot * R + a) * kWave];
+                    const double s = rv - ox;
+#pragma unroll
+                    for (int k = 0; k < M; ++k) u[k] += sK[(c * M + k) * kWave] * s;
+                }
+                slot = (slot + 1 == RC) ? 0 : slot + 1;
+            }
         }
         if (p.U) {
 #pragma unroll
@@ -148,27 +182,37 @@ __global__ __launch_bounds__(kWave) void closed_loop_lane_kernel(LoopArgs p, con
 #undef IN
 }
 
-size_t lane_lds_bytes(int n, int m, int r, int f, bool shared) {
-    const size_t per_lane = (size_t)f * r * (n + m) + (shared ? 0 : (size_t)(f + kChunk) * r);
+// horizons with a register-resident instantiation (the reference scenario's f = 20, main.rs:17)
+template <int N, int M, int R>
+constexpr int static_horizon() { return (M == 1 && R == 1 && (N == 2 || N == 4)) ? 20 : 0; }
+
+size_t lane_lds_bytes(int n, int m, int r, int f, bool shared, bool in_regs) {
+    const size_t per_lane = (in_regs ? 0 : (size_t)f * r * (n + m)) + (shared ? 0 : (size_t)(f + kChunk) * r);
     return per_lane * kWave * sizeof(double);
+}
+
+template <int N, int M, int R, bool SHARED, int FS>
+int launch_lane_inst(const LoopArgs &a, hipStream_t s) {
+    const long long blocks = (a.batch + kWave - 1) / kWave;
+    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    const size_t lds_bytes = lane_lds_bytes(N, M, R, a.f, SHARED, FS > 0);
+    if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)closed_loop_lane_kernel<N, M, R, SHARED, FS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((closed_loop_lane_kernel<N, M, R, SHARED, FS>), dim3((unsigned)blocks), dim3(kWave), lds_bytes, s, a, a.ref);
+    return (int)hipGetLastError();
 }
 
 template <int N, int M, int R>
 int launch_lane_one(const LoopArgs &a, hipStream_t s) {
-    const long long blocks = (a.batch + kWave - 1) / kWave;
-    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-    const size_t lds_bytes = lane_lds_bytes(N, M, R, a.f, a.ref_shared != 0);
-    const void *fn = a.ref_shared ? (const void *)closed_loop_lane_kernel<N, M, R, true>
-                                  : (const void *)closed_loop_lane_kernel<N, M, R, false>;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
+    constexpr int FS = static_horizon<N, M, R>();
+    if constexpr (FS > 0) {
+        if (a.f == FS) return a.ref_shared ? launch_lane_inst<N, M, R, true, FS>(a, s) : launch_lane_inst<N, M, R, false, FS>(a, s);
     }
-    if (a.ref_shared)
-        hipLaunchKernelGGL((closed_loop_lane_kernel<N, M, R, true>), dim3((unsigned)blocks), dim3(kWave), lds_bytes, s, a, a.ref);
-    else
-        hipLaunchKernelGGL((closed_loop_lane_kernel<N, M, R, false>), dim3((unsigned)blocks), dim3(kWave), lds_bytes, s, a, a.ref);
-    return (int)hipGetLastError();
+    return a.ref_shared ? launch_lane_inst<N, M, R, true, 0>(a, s) : launch_lane_inst<N, M, R, false, 0>(a, s);
 }
 
 // One wavefront per instance.  LDS: A, B, C, Phi, first m gain rows, two state buffers, s, u, the reference ring
@@ -306,7 +350,6 @@ size_t group_lds_bytes(const LoopArgs &a) {
 
 int launch_closed_loop_lane(const LoopArgs &a, hipStream_t s) {
     if (!qp_lane_supports(a.n, a.m, a.r)) return MPCX_ERR_UNSUPPORTED;
-    if (lane_lds_bytes(a.n, a.m, a.r, a.f, a.ref_shared != 0) > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
 #define CASE(N_, M_, R_) \
     if (a.n == N_ && a.m == M_ && a.r == R_) return launch_lane_one<N_, M_, R_>(a, s);
     CASE(1, 1, 1) CASE(2, 1, 1) CASE(3, 1, 1) CASE(4, 1, 1) CASE(5, 1, 1) CASE(6, 1, 1)
