@@ -81,11 +81,12 @@ __global__ __launch_bounds__(kWave) void closed_loop_lane_kernel(LoopArgs p, con
         for (long long tau = 0; tau < first; ++tau)
 #pragma unroll
             for (int a = 0; a < R; ++a) sRing[((int)(tau % RC) * R + a) * kWave] = IN(p.ref, ER, tau * R + a);
+        // branch-free: a column beyond the trajectory reads the (valid, never used) last column instead
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
-            const long long tau = kChunk + F - 1 + q;
+            const long long tau = kChunk + F - 1 + q, tc = tau < L ? tau : L - 1;
 #pragma unroll
-            for (int a = 0; a < R; ++a) pre[q][a] = (tau < L) ? IN(p.ref, ER, tau * R + a) : 0.0;
+            for (int a = 0; a < R; ++a) pre[q][a] = IN(p.ref, ER, tc * R + a);
         }
     }
 
@@ -106,9 +107,9 @@ __global__ __launch_bounds__(kWave) void closed_loop_lane_kernel(LoopArgs p, con
             }
 #pragma unroll
             for (int q = 0; q < kChunk; ++q) {
-                const long long tau = t + kChunk + F - 1 + q;
+                const long long tau = t + kChunk + F - 1 + q, tc = tau < L ? tau : L - 1;
 #pragma unroll
-                for (int a = 0; a < R; ++a) pre[q][a] = (tau < L) ? IN(p.ref, ER, tau * R + a) : 0.0;
+                for (int a = 0; a < R; ++a) pre[q][a] = IN(p.ref, ER, tc * R + a);
             }
         }
         double u[M];
@@ -252,9 +253,9 @@ __global__ __launch_bounds__(kWave) void closed_loop_group_kernel(LoopArgs p, co
         const long long first = (kChunk + F - 1 < L) ? kChunk + F - 1 : L;
         for (long long e = lane; e < first * r; e += kWave) sRing[(int)((e / r) % RC) * r + (int)(e % r)] = IN(p.ref, ER, e);
 #pragma unroll
-        for (int q = 0; q < kChunk; ++q) {
+        for (int q = 0; q < kChunk; ++q) {  // branch-free, clamped to valid (unused) addresses
             const long long tau = kChunk + F - 1 + q;
-            pre[q] = (lane < r && tau < L) ? IN(p.ref, ER, tau * r + lane) : 0.0;
+            pre[q] = IN(p.ref, ER, (tau < L ? tau : L - 1) * r + (lane < r ? lane : 0));
         }
     }
     lds_barrier();
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(kWave) void closed_loop_group_kernel(LoopArgs p, co
 #pragma unroll
             for (int q = 0; q < kChunk; ++q) {
                 const long long tau = t0 + kChunk + F - 1 + q;
-                pre[q] = (lane < r && tau < L) ? IN(p.ref, ER, tau * r + lane) : 0.0;
+                pre[q] = IN(p.ref, ER, (tau < L ? tau : L - 1) * r + (lane < r ? lane : 0));
             }
             lds_barrier();
         }
