@@ -21,6 +21,10 @@ struct SolveArgs {
     long long batch, W;
     int nrow, nrhs;
     int negate;
+    // gain: R is Gamma ((nrhs) x (nrow) per instance, column-major) and the right-hand side Gamma^T blockdiag(Q) is
+    // formed while loading; Q is r x r.  Otherwise Q = nullptr and R is the (nrow x nrhs) right-hand side itself.
+    const double *Q;
+    int r;
 };
 
 __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs p) {
@@ -95,6 +99,154 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs p) {
     if (p.info && lane == 0) p.info[b] = failed ? 1 : 0;
 }
 
+// Systems of up to 64 unknowns: G = 16, 32 or 64 lanes per instance, lane i owns row i of [H | R], held row-major in LDS
+// (so a lane's sweep along its row and the broadcast of the pivot row are 16-byte LDS accesses).  Gauss-Jordan with
+// partial pivoting and implicit row exchanges: at step k the pivot is the largest |a[i][k]| among the rows that have not
+// been a pivot yet (the same set nalgebra's LU searches; on an exact tie the lowest physical row wins, where nalgebra
+// takes the first row in exchanged order), every other row is reduced, and no back substitution is needed.  A group
+// never spans wavefronts and LDS operations of a wavefront execute in order, so the steps need no workgroup barrier.
+// A workgroup serves `ipb` consecutive instances and moves them between HBM and LDS cooperatively, so that in the
+// batch-interleaved layouts one access covers the same element of all its instances.
+template <int G>
+__global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs p, int ipb, int ldr) {
+    extern __shared__ __align__(16) double rows[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int nr = p.nrow, nrhs = p.nrhs, nc = nr + nrhs;
+    const long long b0 = (long long)blockIdx.x * ipb;
+    const int live = (p.batch - b0 < ipb) ? (int)(p.batch - b0) : ipb;
+    const size_t per_inst = (size_t)nr * ldr;
+    const int EH = nr * nr, ER = nr * nrhs;
+    // ---- HBM -> LDS (transposing: element e = col * nr + row of a column-major matrix goes to row * ldr + col)
+    auto load = [&](const double *src, int E, int col0) {
+        if (p.W > 1) {  // instance fastest: one access = the same element of all instances of the block
+            const int step = nthreads / ipb, inst = tid % ipb;
+            int e = tid / ipb, col = e / nr, row = e - col * nr;
+            const int dcol = step / nr, drow = step - dcol * nr;
+            const double *sp = src + elem_index(b0 + (inst < live ? inst : 0), 0, E, p.W);  // element e is e * W further
+            for (; e < E; e += step) {
+                if (inst < live) rows[inst * per_inst + (size_t)row * ldr + col0 + col] = sp[(long long)e * p.W];
+                col += dcol;
+                row += drow;
+                if (row >= nr) { row -= nr; ++col; }
+            }
+        } else {  // instance-major: one instance at a time, elements fastest
+            const int dcol = nthreads / nr, drow = nthreads - dcol * nr;
+            for (int inst = 0; inst < live; ++inst) {
+                int e = tid, col = e / nr, row = e - col * nr;
+                const double *sp = src + (b0 + inst) * (long long)E;
+                for (; e < E; e += nthreads) {
+                    rows[inst * per_inst + (size_t)row * ldr + col0 + col] = sp[e];
+                    col += dcol;
+                    row += drow;
+                    if (row >= nr) { row -= nr; ++col; }
+                }
+            }
+        }
+    };
+    load(p.H, EH, 0);
+    if (p.Q == nullptr) {
+        load(p.R, ER, nr);
+    } else {
+        // right-hand side column c = (blk, a2), row k:  sum_a Gamma[blk r + a][k] Q[a][a2]   (controller.rs:96, M^T W4)
+        const int r = p.r, fr = nrhs;
+        if (p.W > 1) {
+            const int step = nthreads / ipb, inst = tid % ipb;
+            const double *sp = p.R + elem_index(b0 + (inst < live ? inst : 0), 0, ER, p.W);
+            int e = tid / ipb, k = e / fr, c = e - k * fr;  // e = k * fr + c, as Gamma is stored
+            const int dk = step / fr, dc = step - dk * fr;
+            for (; e < ER; e += step) {
+                if (inst < live) {
+                    const int blk = c / r, a2 = c - blk * r;
+                    double acc = 0.0;
+                    for (int a = 0; a < r; ++a) acc += sp[(long long)(k * fr + blk * r + a) * p.W] * p.Q[a2 * r + a];
+                    rows[inst * per_inst + (size_t)k * ldr + nr + c] = acc;
+                }
+                k += dk;
+                c += dc;
+                if (c >= fr) { c -= fr; ++k; }
+            }
+        } else {
+            const int dk = nthreads / fr, dc = nthreads - dk * fr;
+            for (int inst = 0; inst < live; ++inst) {
+                const double *sp = p.R + (b0 + inst) * (long long)ER;
+                int e = tid, k = e / fr, c = e - k * fr;
+                for (; e < ER; e += nthreads) {
+                    const int blk = c / r, a2 = c - blk * r;
+                    double acc = 0.0;
+                    for (int a = 0; a < r; ++a) acc += sp[k * fr + blk * r + a] * p.Q[a2 * r + a];
+                    rows[inst * per_inst + (size_t)k * ldr + nr + c] = acc;
+                    k += dk;
+                    c += dc;
+                    if (c >= fr) { c -= fr; ++k; }
+                }
+            }
+        }
+    }
+    lds_barrier();
+
+    const int g = tid / G, i = tid % G;          // instance within the block, row
+    const bool active = g < live && i < nr;
+    double *inst_a = rows + (size_t)(g < ipb ? g : 0) * per_inst;
+    double *arow = inst_a + (size_t)(i < nr ? i : 0) * ldr;
+    const int lane = tid & 63, gbase = lane - i;  // first lane of this group within the wavefront
+    bool done = false, failed = false;
+    int mycol = 0;
+    for (int k = 0; k < nr; ++k) {
+        double cand = -1.0;
+        if (active && !done) {
+            const double a = fabs(arow[k]);
+            cand = (a == a) ? a : INFINITY;  // a NaN must be picked (and then fail), not skipped
+        }
+        double best = cand;
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off));
+        const unsigned long long votes = __ballot(cand == best && active && !done);
+        const unsigned long long mine = (G == 64) ? votes : ((votes >> gbase) & ((1ull << G) - 1ull));
+        const int prow = mine ? __ffsll((long long)mine) - 1 : 0;
+        const double *pr = inst_a + (size_t)prow * ldr;
+        const double piv = pr[k];
+        if (!(best > 0.0) || !isfinite(best)) failed = true;  // zero or non-finite pivot: the reference's inversion error
+        if (i == prow && !failed) { done = true; mycol = k; }
+        const double m = (active && i != prow && !failed) ? arow[k] / piv : 0.0;
+        // a[i][j] -= m a[prow][j] for j > k, two columns per access; an odd start also rewrites column k (never read again)
+        int j = (k + 1) & ~1;
+        for (; j + 8 <= nc; j += 8) {
+            const double2 p0 = *(const double2 *)(pr + j), p1 = *(const double2 *)(pr + j + 2);
+            const double2 p2 = *(const double2 *)(pr + j + 4), p3 = *(const double2 *)(pr + j + 6);
+            double2 a0 = *(double2 *)(arow + j), a1 = *(double2 *)(arow + j + 2);
+            double2 a2 = *(double2 *)(arow + j + 4), a3 = *(double2 *)(arow + j + 6);
+            a0.x -= m * p0.x; a0.y -= m * p0.y; a1.x -= m * p1.x; a1.y -= m * p1.y;
+            a2.x -= m * p2.x; a2.y -= m * p2.y; a3.x -= m * p3.x; a3.y -= m * p3.y;
+            if (active) {
+                *(double2 *)(arow + j) = a0; *(double2 *)(arow + j + 2) = a1;
+                *(double2 *)(arow + j + 4) = a2; *(double2 *)(arow + j + 6) = a3;
+            }
+        }
+        for (; j < nc; j += 2) {  // ldr is even and >= nc + 1: the pair never leaves the row
+            const double2 p0 = *(const double2 *)(pr + j);
+            double2 a0 = *(double2 *)(arow + j);
+            a0.x -= m * p0.x; a0.y -= m * p0.y;
+            if (active) *(double2 *)(arow + j) = a0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // the row that was the pivot of step k holds unknown k: x[k][c] = a[row][nr + c] / a[row][k]
+    if (active) {
+        const double sign = p.negate ? -1.0 : 1.0;
+        const double inv = 1.0 / arow[mycol];
+        const long long b = b0 + g;
+        double *xp = p.X + elem_index(b, failed ? i : mycol, ER, p.W);
+        const long long xstep = (long long)nr * p.W;
+        for (int c = 0; c < nrhs; ++c) {
+            const double x = failed ? __longlong_as_double(0x7ff8000000000000LL) : sign * (arow[nr + c] * inv);
+            xp[c * xstep] = x;
+        }
+        if (p.info && i == 0) p.info[b] = failed ? 1 : 0;
+    }
+}
+
 // R[c][(i, a2)] = sum_a Gamma[(i, a)][c] Q[a][a2]  (Gamma^T blockdiag(Q)), written to `out` in the batch layout
 __global__ __launch_bounds__(256) void gamma_t_q_kernel(const double *Gamma, const double *Q, double *out, long long batch,
                                                         long long W, int m, int r, int f, int v) {
@@ -111,7 +263,37 @@ __global__ __launch_bounds__(256) void gamma_t_q_kernel(const double *Gamma, con
     out[elem_index(b, e, per, W)] = s;
 }
 
+template <int G>
+int launch_small(const SolveArgs &a, hipStream_t s) {
+    const int nc = a.nrow + a.nrhs;
+    int ldr = nc + 1;
+    while ((ldr & 3) != 2) ++ldr;  // even (16-byte pairs) and 2 mod 4 (rows land on distinct LDS banks)
+    const size_t per_inst = (size_t)a.nrow * ldr * sizeof(double);
+    // instances per workgroup: the choice that keeps most instances resident on a CU (160 KB of LDS, 32 wavefronts);
+    // on a tie the larger group, whose accesses to the interleaved layouts are wider
+    int ipb = 0;
+    size_t best = 0;
+    for (int c = 16; c >= 1; c >>= 1) {
+        if (per_inst * c > 64 * 1024 || c * G > 1024) continue;
+        const size_t by_lds = (160 * 1024) / (per_inst * c), by_waves = (size_t)(32 * 64) / (size_t)(c * G < 64 ? 64 : c * G);
+        const size_t resident = (by_lds < by_waves ? by_lds : by_waves) * c;
+        if (resident > best) { best = resident; ipb = c; }
+    }
+    if (ipb == 0) return MPCX_ERR_UNSUPPORTED;
+    const long long blocks = (a.batch + ipb - 1) / ipb;
+    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    int threads = ipb * G;
+    if (threads < 64) threads = 64;
+    hipLaunchKernelGGL(solve_small_kernel<G>, dim3((unsigned)blocks), dim3(threads), per_inst * ipb, s, a, ipb, ldr);
+    return (int)hipGetLastError();
+}
+
 int launch_solve(const SolveArgs &a, hipStream_t s) {
+    if (a.nrow <= 64) {
+        const int rc = a.nrow <= 16 ? launch_small<16>(a, s) : a.nrow <= 32 ? launch_small<32>(a, s) : launch_small<64>(a, s);
+        if (rc != MPCX_ERR_UNSUPPORTED) return rc;
+    }
+    if (a.Q) return MPCX_ERR_UNSUPPORTED;  // the general kernel takes a ready right-hand side
     const int ld = a.nrow | 1;
     const size_t lds_bytes = (size_t)ld * (a.nrow + a.nrhs) * sizeof(double);
     if (lds_bytes > 160 * 1024 || a.batch > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
@@ -127,7 +309,7 @@ int launch_solve(const SolveArgs &a, hipStream_t s) {
 
 int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *info, long long batch, long long W, int vm,
                     hipStream_t s) {
-    SolveArgs a{H, fvec, u_seq, info, batch, W, vm, 1, 1};
+    SolveArgs a{H, fvec, u_seq, info, batch, W, vm, 1, 1, nullptr, 0};
     return launch_solve(a, s);
 }
 
@@ -140,10 +322,15 @@ int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double
         const int nr = v * m, ld = nr | 1;
         if ((size_t)ld * (nr + f * r) * sizeof(double) > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
     }
+    if (v * m <= 64) {  // small systems: Gamma^T W4 is formed while the workgroup loads its instances
+        SolveArgs a{H, Gamma, gain, info, batch, W, v * m, f * r, 0, Q, r};
+        const int rc = launch_solve(a, s);
+        if (rc != MPCX_ERR_UNSUPPORTED) return rc;
+    }
     hipLaunchKernelGGL(gamma_t_q_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Gamma, Q, gain, batch, W, m, r, f, v);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    SolveArgs a{H, gain, gain, info, batch, W, v * m, f * r, 0};  // in place: R is read into LDS before X is written
+    SolveArgs a{H, gain, gain, info, batch, W, v * m, f * r, 0, nullptr, 0};  // in place: R is read into LDS before X is written
     return launch_solve(a, s);
 }
 
