@@ -13,6 +13,8 @@ struct mpcx_ctx {
     hipStream_t stream;
     void *work;          // staging for host-pointer calls
     size_t work_bytes;
+    void *lu_work;       // augmented matrices of the blocked solver (systems beyond 64 unknowns)
+    size_t lu_bytes;
     void *stat_scratch;  // partial records of the stats reduction + one result record
     char err[512];
 };
@@ -52,6 +54,28 @@ int check_common(mpcx_ctx *ctx, const mpcx_dims *d, long long *W) {
     if (w != 1 && w != d->batch && (w % 64) != 0)
         return fail(ctx, MPCX_ERR_LAYOUT, "interleave %lld: must be 0 (= batch), 1, or a multiple of 64", (long long)d->interleave);
     *W = w;
+    return MPCX_OK;
+}
+
+// Workspace of the blocked solver: room for the whole batch when that is at most kLuCap, else for as many instances
+// as kLuCap holds (the solver then runs the batch in several launches); never less than one instance.
+constexpr size_t kLuCap = (size_t)16 << 30;
+int ensure_lu_work(mpcx_ctx *ctx, int nr, int nrhs, long long batch, size_t *doubles) {
+    *doubles = 0;
+    if (solve_fits_on_chip(nr, nrhs) || !solve_large_supports(nr)) return MPCX_OK;
+    const size_t per = solve_large_ws_doubles(nr, nrhs) * sizeof(double);
+    size_t want = per * (size_t)batch;
+    if (want > kLuCap) want = (kLuCap / per ? kLuCap / per : 1) * per;
+    if (want > ctx->lu_bytes) {
+        if (ctx->lu_work) {
+            HIP_TRY(ctx, hipFree(ctx->lu_work));
+            ctx->lu_work = nullptr;
+            ctx->lu_bytes = 0;
+        }
+        HIP_TRY(ctx, hipMalloc(&ctx->lu_work, want));
+        ctx->lu_bytes = want;
+    }
+    *doubles = ctx->lu_bytes / sizeof(double);
     return MPCX_OK;
 }
 
@@ -116,6 +140,8 @@ int mpcx_create(mpcx_ctx **out, int device_id) {
     ctx->device = device_id;
     ctx->work = nullptr;
     ctx->work_bytes = 0;
+    ctx->lu_work = nullptr;
+    ctx->lu_bytes = 0;
     ctx->stat_scratch = nullptr;
     ctx->err[0] = 0;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -138,6 +164,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->lu_work) (void)hipFree(ctx->lu_work);
     if (ctx->stat_scratch) (void)hipFree(ctx->stat_scratch);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -340,8 +367,11 @@ int mpcx_qp_solve_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, co
     if (d->batch == 0) return MPCX_OK;
     if (!H || !fvec || !u_seq) return fail(ctx, MPCX_ERR_NULL, "H, fvec and u_seq are required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    rc = launch_qp_solve(H, fvec, u_seq, info, d->batch, W, d->v * d->m, (hipStream_t)stream);
-    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "solve: v m = %d does not fit LDS", d->v * d->m);
+    size_t wsd = 0;
+    rc = ensure_lu_work(ctx, d->v * d->m, 1, d->batch, &wsd);
+    if (rc != MPCX_OK) return rc;
+    rc = launch_qp_solve(H, fvec, u_seq, info, d->batch, W, d->v * d->m, (double *)ctx->lu_work, wsd, (hipStream_t)stream);
+    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "solve: v m = %d is beyond what the solver holds on chip", d->v * d->m);
     if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "solve launch");
     return MPCX_OK;
 }
@@ -356,8 +386,11 @@ int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, con
     if (d->batch == 0) return MPCX_OK;
     if (!H || !Gamma || !W4 || !gain) return fail(ctx, MPCX_ERR_NULL, "H, Gamma, W4 and gain are required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    rc = launch_qp_gain(H, Gamma, W4, gain, info, d->batch, W, d->m, d->r, d->f, d->v, (hipStream_t)stream);
-    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "gain: (v m)(v m + f r) = %d x %d does not fit LDS", d->v * d->m, d->v * d->m + d->f * d->r);
+    size_t wsd = 0;
+    rc = ensure_lu_work(ctx, d->v * d->m, d->f * d->r, d->batch, &wsd);
+    if (rc != MPCX_OK) return rc;
+    rc = launch_qp_gain(H, Gamma, W4, gain, info, d->batch, W, d->m, d->r, d->f, d->v, (double *)ctx->lu_work, wsd, (hipStream_t)stream);
+    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "gain: v m = %d is beyond what the solver holds on chip", d->v * d->m);
     if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "gain launch");
     return MPCX_OK;
 }

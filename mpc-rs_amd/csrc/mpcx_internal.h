@@ -41,10 +41,17 @@ int launch_qp_lane(const QpArgs &a, hipStream_t s);
 int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s);
 int launch_hessian_mfma(const QpArgs &a, hipStream_t s);
 int launch_qp_dense(const QpArgs &a, hipStream_t s);
+// ws / ws_doubles: device workspace for systems beyond 64 unknowns (solve_large_ws_doubles per instance; fewer
+// instances' worth means more launches); ignored by the on-chip kernels.
 int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *info, long long batch, long long W, int vm,
-                    hipStream_t s);
+                    double *ws, size_t ws_doubles, hipStream_t s);
 int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double *gain, int *info, long long batch,
-                   long long W, int m, int r, int f, int v, hipStream_t s);
+                   long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s);
+bool solve_fits_on_chip(int nr, int nrhs);
+size_t solve_large_ws_doubles(int nr, int nrhs);
+bool solve_large_supports(int nr);
+int launch_solve_large(const double *H, const double *R, const double *Q, int r, double *X, int *info, long long batch,
+                       long long W, int nr, int nrhs, int negate, double *ws, size_t ws_doubles, hipStream_t s);
 int launch_closed_loop_lane(const LoopArgs &a, hipStream_t s);
 int launch_closed_loop_group(const LoopArgs &a, hipStream_t s);
 int launch_rollout_lane(const RolloutArgs &a, hipStream_t s);

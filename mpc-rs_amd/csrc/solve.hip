@@ -307,31 +307,42 @@ int launch_solve(const SolveArgs &a, hipStream_t s) {
 
 }  // namespace
 
+// True when one of the LDS-resident kernels takes the system, i.e. no device workspace is needed.
+bool solve_fits_on_chip(int nr, int nrhs) {
+    int ldr = nr + nrhs + 1;
+    while ((ldr & 3) != 2) ++ldr;
+    if (nr <= 64 && (size_t)nr * ldr * sizeof(double) <= 64 * 1024) return true;
+    return (size_t)(nr | 1) * (nr + nrhs) * sizeof(double) <= 160 * 1024;
+}
+
 int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *info, long long batch, long long W, int vm,
-                    hipStream_t s) {
+                    double *ws, size_t ws_doubles, hipStream_t s) {
     SolveArgs a{H, fvec, u_seq, info, batch, W, vm, 1, 1, nullptr, 0};
-    return launch_solve(a, s);
+    const int rc = launch_solve(a, s);
+    if (rc != MPCX_ERR_UNSUPPORTED) return rc;
+    return launch_solve_large(H, fvec, nullptr, 0, u_seq, info, batch, W, vm, 1, 1, ws, ws_doubles, s);
 }
 
 int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double *gain, int *info, long long batch,
-                   long long W, int m, int r, int f, int v, hipStream_t s) {
-    const long long total = batch * (long long)(v * m) * (f * r);
-    const long long blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-    {   // the augmented system must fit LDS before anything is launched
-        const int nr = v * m, ld = nr | 1;
-        if ((size_t)ld * (nr + f * r) * sizeof(double) > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
-    }
-    if (v * m <= 64) {  // small systems: Gamma^T W4 is formed while the workgroup loads its instances
-        SolveArgs a{H, Gamma, gain, info, batch, W, v * m, f * r, 0, Q, r};
+                   long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s) {
+    const int nr = v * m, nrhs = f * r;
+    if (nr <= 64) {  // small systems: Gamma^T W4 is formed while the workgroup loads its instances
+        SolveArgs a{H, Gamma, gain, info, batch, W, nr, nrhs, 0, Q, r};
         const int rc = launch_solve(a, s);
         if (rc != MPCX_ERR_UNSUPPORTED) return rc;
     }
-    hipLaunchKernelGGL(gamma_t_q_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Gamma, Q, gain, batch, W, m, r, f, v);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    SolveArgs a{H, gain, gain, info, batch, W, v * m, f * r, 0, nullptr, 0};  // in place: R is read into LDS before X is written
-    return launch_solve(a, s);
+    const int ld = nr | 1;
+    if ((size_t)ld * (nr + nrhs) * sizeof(double) <= 160 * 1024) {  // fits the one-wavefront LDS kernel
+        const long long total = batch * (long long)nr * nrhs;
+        const long long blocks = (total + 255) / 256;
+        if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(gamma_t_q_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Gamma, Q, gain, batch, W, m, r, f, v);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        SolveArgs a{H, gain, gain, info, batch, W, nr, nrhs, 0, nullptr, 0};  // in place: R is read into LDS before X is written
+        return launch_solve(a, s);
+    }
+    return launch_solve_large(H, Gamma, Q, r, gain, info, batch, W, nr, nrhs, 0, ws, ws_doubles, s);
 }
 
 }  // namespace mpcx

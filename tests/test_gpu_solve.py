@@ -68,3 +68,41 @@ def test_singular_instances_are_flagged_not_fatal(ctx):
     _, info = ctx.qp_gain(qp["H"], qp["Gamma"], np.eye(2), 2, 2, 2, 2)
     st, *_ = orc.form_lifted_matrices(A, B, C, 2, 2, np.zeros((4, 4)), np.eye(4))
     assert info[0] == 1 and st == orc.ORC_ERR_INVERSION
+
+
+@pytest.mark.parametrize("vm,m,fr,r,il", [(65, 1, 70, 1, 1), (100, 2, 150, 3, 1), (130, 1, 140, 1, 0), (200, 4, 600, 12, 1), (48, 1, 500, 1, 1)])
+def test_large_systems_blocked_solver(ctx, vm, m, fr, r, il):
+    """Beyond 64 unknowns (or right-hand sides that do not fit LDS): the blocked solver on a device workspace."""
+    rng = np.random.default_rng(vm + fr)
+    batch = 5
+    v, f = vm // m, fr // r
+    H = rng.standard_normal((batch, vm, vm))
+    H[:, 0, 0] = 0.0                                  # row exchange in the very first step
+    H[:, 17, :] *= 1e-3                               # a badly scaled row: pivoting matters
+    fv = rng.standard_normal((batch, vm))
+    u, info = ctx.qp_solve(H, fv, m, interleave=il)
+    assert np.all(info == 0)
+    ref = np.stack([-np.linalg.solve(H[b], fv[b]) for b in range(batch)])
+    cond = max(np.linalg.cond(h) for h in H)
+    assert rel_fro(u, ref) <= 1e-11 * cond
+    Gamma = rng.standard_normal((batch, fr, vm))
+    Q = rng.standard_normal((r, r))
+    gain, info = ctx.qp_gain(H, Gamma, Q, m, r, f, v, interleave=il)
+    assert np.all(info == 0)
+    w4 = np.kron(np.eye(f), Q)
+    want = np.stack([np.linalg.solve(H[b], Gamma[b].T @ w4) for b in range(batch)])
+    assert rel_fro(gain, want) <= 1e-11 * cond
+
+
+def test_large_singular_is_flagged(ctx):
+    rng = np.random.default_rng(8)
+    batch, vm = 4, 96
+    H = rng.standard_normal((batch, vm, vm)) + 10 * np.eye(vm)
+    H[1, :, 40] = 0.0
+    H[2, 70, :] = H[2, 3, :]                          # two equal rows: an exactly zero pivot late in the elimination
+    fv = rng.standard_normal((batch, vm))
+    u, info = ctx.qp_solve(H, fv, 1)
+    assert list(info) == [0, 1, 1, 0]
+    assert np.all(np.isnan(u[1])) and np.all(np.isnan(u[2]))
+    ref = np.stack([-np.linalg.solve(H[b], fv[b]) for b in (0, 3)])
+    assert rel_fro(u[[0, 3]], ref) <= 1e-10
