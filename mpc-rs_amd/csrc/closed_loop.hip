@@ -11,7 +11,7 @@
 // Time is serial, parallelism comes from the batch.  Two kernels, as for the open-loop rollout:
 //   closed_loop_lane   tiny plants: one lane per instance; A, B, C, x in registers; Phi and the first gain rows in a
 //                      per-lane LDS column (no barriers: a lane only ever touches its own column).
-//   closed_loop_group  any n, m, r <= 64: one wavefront per instance, everything in LDS.
+//   closed_loop_group  any n, m, r <= 64: one workgroup of four wavefronts per instance, everything in LDS.
 // Loads and stores of a wave retire through one in-order counter, so a load issued after a store cannot be consumed
 // before that store has reached memory.  Both kernels therefore fetch the per-instance reference a chunk of kChunk
 // steps ahead: the wait for a chunk's loads only covers stores that are a whole chunk old.  A reference shared by the
@@ -216,52 +216,61 @@ int launch_lane_one(const LoopArgs &a, hipStream_t s) {
     return a.ref_shared ? launch_lane_inst<N, M, R, true, 0>(a, s) : launch_lane_inst<N, M, R, false, 0>(a, s);
 }
 
-// One wavefront per instance.  LDS: A, B, C, Phi, first m gain rows, two state buffers, s, u, the reference ring
-// and a staging area holding kChunk steps of outputs, flushed in one burst per chunk.
-__global__ __launch_bounds__(kWave) void closed_loop_group_kernel(LoopArgs p, const double *__restrict__ ref_shared) {
+// One workgroup of four wavefronts per instance.  LDS: A, B, C, Phi, the first m gain rows, two state buffers, s, u,
+// per-wavefront partial sums, the reference ring and a staging area holding kChunk steps of outputs.
+// The last wavefront alone fetches the reference (a chunk ahead, into registers, then into the ring) and takes no part
+// in flushing the outputs: its memory counter then only ever holds loads, so waiting for them never waits for a store.
+constexpr int kGroupThreads = 256;
+constexpr int kGroupWaves = kGroupThreads / kWave;
+constexpr int kRowsPerPass = 4;  // rows of s a thread carries at once
+
+__global__ __launch_bounds__(kGroupThreads) void closed_loop_group_kernel(LoopArgs p) {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long b = blockIdx.x;
     const int n = p.n, m = p.m, r = p.r, F = p.f, FR = F * r, VM = p.v * m;
     const long long W = p.W, tile = b / W, li = b - tile * W, T = p.T;
     const long long L = T + F, ER = (long long)r * L;
     const int RC = F + kChunk;
-    const bool shared = p.ref_shared != 0;
 #define IN(ptr, E, e) ((ptr)[tile * (long long)(E) * W + (long long)(e) * W + li])
     double *sA = lds, *sB = sA + n * n, *sC = sB + n * m, *sPhi = sC + r * n, *sK = sPhi + (size_t)FR * n;
-    double *sx = sK + (size_t)FR * m, *ss = sx + 2 * n, *su = ss + FR, *sOut = su + m;
+    double *sx = sK + (size_t)FR * m, *ss = sx + 2 * n, *su = ss + FR, *sPart = su + m, *sOut = sPart + kGroupWaves * 4;
     const int out_per_step = n + m + r;
     double *sRing = sOut + kChunk * out_per_step;  // (tau % RC) * r + a
-    for (int e = lane; e < n * n; e += kWave) sA[e] = IN(p.A, n * n, e);
-    for (int e = lane; e < n * m; e += kWave) sB[e] = IN(p.B, n * m, e);
-    for (int e = lane; e < r * n; e += kWave) sC[e] = IN(p.C, r * n, e);
-    for (int e = lane; e < FR * n; e += kWave) sPhi[e] = IN(p.Phi, (long long)FR * n, e);
-    for (int e = lane; e < FR * m; e += kWave) {  // sK[c * m + k] = gain(k, c)
+    for (int e = tid; e < n * n; e += kGroupThreads) sA[e] = IN(p.A, n * n, e);
+    for (int e = tid; e < n * m; e += kGroupThreads) sB[e] = IN(p.B, n * m, e);
+    for (int e = tid; e < r * n; e += kGroupThreads) sC[e] = IN(p.C, r * n, e);
+    for (int e = tid; e < FR * n; e += kGroupThreads) sPhi[e] = IN(p.Phi, (long long)FR * n, e);
+    for (int e = tid; e < FR * m; e += kGroupThreads) {  // sK[c * m + k] = gain(k, c)
         const int c = e / m, k = e - c * m;
         sK[e] = IN(p.gain, (long long)VM * FR, (long long)c * VM + k);
     }
     const long long EX = (long long)n * (T + 1), EY = (long long)r * T, EU = (long long)m * T;
-    if (lane < n) {
-        const double x0 = IN(p.x0, n, lane);
-        sx[lane] = x0;
-        if (p.X) IN(p.X, EX, lane) = x0;
+    if (tid < n) {
+        const double x0 = IN(p.x0, n, tid);
+        sx[tid] = x0;
+        if (p.X) IN(p.X, EX, tid) = x0;
     }
-    // reference ring: columns [0, kChunk + F - 1) now; later chunks are fetched one chunk ahead into `pre`
-    // (lane q of the first kChunk * r lanes... r <= 64 and kChunk * r may exceed 64, so each lane keeps kChunk slots)
+    // reference: element (a, tau) at rbase[tau * rstep] for lane a of the last wavefront
+    const bool loader = wv == kGroupWaves - 1;
+    const int la = lane < r ? lane : 0;
+    const double *rbase = p.ref_shared ? p.ref + la : &IN(p.ref, ER, la);
+    const long long rstep = p.ref_shared ? (long long)r : (long long)r * W;
     double pre[kChunk];
-    if (!shared) {
+    if (loader) {
         const long long first = (kChunk + F - 1 < L) ? kChunk + F - 1 : L;
-        for (long long e = lane; e < first * r; e += kWave) sRing[(int)((e / r) % RC) * r + (int)(e % r)] = IN(p.ref, ER, e);
+        for (long long tau = 0; tau < first; ++tau)
+            if (lane < r) sRing[(int)(tau % RC) * r + lane] = rbase[tau * rstep];
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {  // branch-free, clamped to valid (unused) addresses
             const long long tau = kChunk + F - 1 + q;
-            pre[q] = IN(p.ref, ER, (tau < L ? tau : L - 1) * r + (lane < r ? lane : 0));
+            pre[q] = rbase[(tau < L ? tau : L - 1) * rstep];
         }
     }
-    lds_barrier();
+    __syncthreads();
     for (long long t0 = 0; t0 < T; t0 += kChunk) {
         const int steps = (int)((T - t0 < kChunk) ? T - t0 : kChunk);
-        if (!shared && t0 > 0) {
+        if (loader && t0 > 0) {
 #pragma unroll
             for (int q = 0; q < kChunk; ++q) {
                 const long long tau = t0 + F - 1 + q;
@@ -270,28 +279,47 @@ __global__ __launch_bounds__(kWave) void closed_loop_group_kernel(LoopArgs p, co
 #pragma unroll
             for (int q = 0; q < kChunk; ++q) {
                 const long long tau = t0 + kChunk + F - 1 + q;
-                pre[q] = IN(p.ref, ER, (tau < L ? tau : L - 1) * r + (lane < r ? lane : 0));
+                pre[q] = rbase[(tau < L ? tau : L - 1) * rstep];
             }
-            lds_barrier();
         }
+        lds_barrier();
         for (int q = 0; q < steps; ++q) {
             const long long t = t0 + q;
+            const int tmod = (int)(t % RC);
             const double *xc = sx + (t & 1) * n;
             double *xn = sx + ((t + 1) & 1) * n;
             double *out = sOut + q * out_per_step;  // [x_{t+1} (n) | u_t (m) | y_t (r)]
-            // s = ref window - Phi x, lanes along the rows of s; partial sums of u = K s stay in the lane
+            // s = ref window - Phi x: threads along the rows of s, kRowsPerPass rows each per pass, the state read once
+            // per pass; the partial sums of u = K s stay in the thread
             double uacc[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int c = lane; c < FR; c += kWave) {
-                double ox = 0.0;
-                for (int j = 0; j < n; ++j) ox += sPhi[j * FR + c] * xc[j];
-                const int i = c / r, a = c - i * r;
-                const double rv = shared ? ref_shared[(t + i) * r + a] : sRing[(int)((t + i) % RC) * r + a];
-                const double s = rv - ox;
-                if (m <= 4) {
+            for (int c0 = tid; c0 < FR; c0 += kGroupThreads * kRowsPerPass) {
+                double ox[kRowsPerPass];
+                int cc[kRowsPerPass];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) uacc[k] += sK[c * m + (k < m ? k : 0)] * (k < m ? s : 0.0);
-                } else {
-                    ss[c] = s;
+                for (int g = 0; g < kRowsPerPass; ++g) {
+                    ox[g] = 0.0;
+                    const int c = c0 + g * kGroupThreads;
+                    cc[g] = c < FR ? c : FR - 1;  // clamped: surplus rows are computed and dropped
+                }
+                for (int j = 0; j < n; ++j) {
+                    const double xj = xc[j];
+#pragma unroll
+                    for (int g = 0; g < kRowsPerPass; ++g) ox[g] += sPhi[j * FR + cc[g]] * xj;
+                }
+#pragma unroll
+                for (int g = 0; g < kRowsPerPass; ++g) {
+                    const int c = cc[g];
+                    const bool live = c0 + g * kGroupThreads < FR;
+                    // row c = i r + a of the window is column t + i, row a of the trajectory: ring index (t mod RC) r + c
+                    int ri = tmod * r + c;
+                    if (ri >= RC * r) ri -= RC * r;
+                    const double sv = live ? sRing[ri] - ox[g] : 0.0;
+                    if (m <= 4) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) uacc[k] += sK[c * m + (k < m ? k : 0)] * (k < m ? sv : 0.0);
+                    } else if (live) {
+                        ss[c] = sv;
+                    }
                 }
             }
             if (m <= 4) {
@@ -299,41 +327,52 @@ __global__ __launch_bounds__(kWave) void closed_loop_group_kernel(LoopArgs p, co
                 for (int k = 0; k < 4; ++k) {
                     double v = uacc[k];
                     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                    if (lane == 0 && k < m) { su[k] = v; out[n + k] = v; }
+                    if (lane == 0) sPart[wv * 4 + k] = v;
+                }
+                lds_barrier();
+                if (tid < m) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int w = 0; w < kGroupWaves; ++w) v += sPart[w * 4 + tid];
+                    su[tid] = v;
+                    out[n + tid] = v;
                 }
             } else {
                 lds_barrier();
-                if (lane < m) {
+                if (tid < m) {
                     double v = 0.0;
-                    for (int c = 0; c < FR; ++c) v += sK[c * m + lane] * ss[c];
-                    su[lane] = v;
-                    out[n + lane] = v;
+                    for (int c = 0; c < FR; ++c) v += sK[c * m + tid] * ss[c];
+                    su[tid] = v;
+                    out[n + tid] = v;
                 }
             }
             lds_barrier();
-            if (lane < n) {
-                double s = 0.0;
-                for (int j = 0; j < n; ++j) s += sA[j * n + lane] * xc[j];
+            if (tid < n) {
+                double sacc = 0.0;
+                for (int j = 0; j < n; ++j) sacc += sA[j * n + tid] * xc[j];
                 double qv = 0.0;
-                for (int k = 0; k < m; ++k) qv += sB[k * n + lane] * su[k];
-                s += qv;
-                xn[lane] = s;
-                out[lane] = s;
-            }
-            if (lane < r) {
+                for (int k = 0; k < m; ++k) qv += sB[k * n + tid] * su[k];
+                sacc += qv;
+                xn[tid] = sacc;
+                out[tid] = sacc;
+            } else if (tid >= kWave && tid < kWave + r) {  // outputs on the second wavefront
+                const int a = tid - kWave;
                 double y = 0.0;
-                for (int j = 0; j < n; ++j) y += sC[j * r + lane] * xc[j];
-                out[n + m + lane] = y;
+                for (int j = 0; j < n; ++j) y += sC[j * r + a] * xc[j];
+                out[n + m + a] = y;
             }
             lds_barrier();
         }
         // flush the chunk: X columns t0+1 .. t0+steps are contiguous per instance, likewise U and Y
-        if (p.X)
-            for (int e = lane; e < steps * n; e += kWave) IN(p.X, EX, (t0 + 1) * n + e) = sOut[(e / n) * out_per_step + (e % n)];
-        if (p.U)
-            for (int e = lane; e < steps * m; e += kWave) IN(p.U, EU, t0 * m + e) = sOut[(e / m) * out_per_step + n + (e % m)];
-        if (p.Y)
-            for (int e = lane; e < steps * r; e += kWave) IN(p.Y, EY, t0 * r + e) = sOut[(e / r) * out_per_step + n + m + (e % r)];
+        if (!loader) {
+            constexpr int kFlush = kGroupThreads - kWave;
+            if (p.X)
+                for (int e = tid; e < steps * n; e += kFlush) IN(p.X, EX, (t0 + 1) * n + e) = sOut[(e / n) * out_per_step + (e % n)];
+            if (p.U)
+                for (int e = tid; e < steps * m; e += kFlush) IN(p.U, EU, t0 * m + e) = sOut[(e / m) * out_per_step + n + (e % m)];
+            if (p.Y)
+                for (int e = tid; e < steps * r; e += kFlush) IN(p.Y, EY, t0 * r + e) = sOut[(e / r) * out_per_step + n + m + (e % r)];
+        }
         lds_barrier();
     }
 #undef IN
@@ -342,8 +381,7 @@ __global__ __launch_bounds__(kWave) void closed_loop_group_kernel(LoopArgs p, co
 size_t group_lds_bytes(const LoopArgs &a) {
     const size_t fr = (size_t)a.f * a.r;
     size_t d = (size_t)a.n * a.n + (size_t)a.n * a.m + (size_t)a.r * a.n + fr * a.n + fr * a.m + 2 * a.n + fr + a.m +
-               (size_t)kChunk * (a.n + a.m + a.r);
-    if (!a.ref_shared) d += (size_t)(a.f + kChunk) * a.r;
+               kGroupWaves * 4 + (size_t)kChunk * (a.n + a.m + a.r) + (size_t)(a.f + kChunk) * a.r;
     return d * sizeof(double);
 }
 
@@ -370,7 +408,7 @@ int launch_closed_loop_group(const LoopArgs &a, hipStream_t s) {
                                            (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(closed_loop_group_kernel, dim3((unsigned)a.batch), dim3(kWave), lds_bytes, s, a, a.ref);
+    hipLaunchKernelGGL(closed_loop_group_kernel, dim3((unsigned)a.batch), dim3(kGroupThreads), lds_bytes, s, a);
     return (int)hipGetLastError();
 }
 
