@@ -146,6 +146,31 @@ int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, 
                          double *gain, int32_t *info, void *stream);
 
 /*
+ * Backward-Euler discretisation, batched: A = (I - Ac dt)^-1, B = A (Bc dt), the last three lines of both
+ * Model::new (model.rs:55-57, :138-140).  Ac is n x n, Bc n x m per instance (dims->n, m, batch, interleave).
+ * `info` as for mpcx_qp_solve: 1 marks an instance whose matrix could not be inverted (the reference unwraps the
+ * failed try_inverse and panics, model.rs:56); its A and B are NaN.
+ */
+int mpcx_c2d_backward_euler_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *Ac, const double *Bc, double dt,
+                                double *A, double *B, int32_t *info);
+int mpcx_c2d_backward_euler_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *Ac, const double *Bc, double dt,
+                                    double *A, double *B, int32_t *info, void *stream);
+
+/*
+ * The reference's two plants from per-instance physical parameters, discretised: dc_motor::Model::new
+ * (model.rs:45-66; parameters b, j, k, l, r in that order; n = 2) and mpc::Model::new (model.rs:126-149; m1, m2, k1,
+ * k2, d1, d2; n = 4).  m = r = 1.  `params` holds 5 resp. 6 values per instance in the batch layout; A (n x n),
+ * B (n x 1) and C (1 x n, may be NULL) come out in the same layout.  The reference keeps the parameter fields private
+ * (model.rs:16-22, :95-102) and only offers the defaults; this is the constructor a parameter sweep needs.
+ */
+#define MPCX_PLANT_DC_MOTOR 0
+#define MPCX_PLANT_TWO_MASS 1
+int mpcx_plants_f64(mpcx_ctx *ctx, int kind, int64_t batch, int64_t interleave, const double *params, double dt, double *A,
+                    double *B, double *C, int32_t *info);
+int mpcx_plants_f64_dev(mpcx_ctx *ctx, int kind, int64_t batch, int64_t interleave, const double *params, double dt,
+                        double *A, double *B, double *C, int32_t *info, void *stream);
+
+/*
  * Receding-horizon closed loop, batched: the loop of src/main.rs:51-71 for `batch` plants at once.  For t = 0 .. T-1:
  *     s = ref[:, t .. t+f) - Phi x_t; u_t = first m entries of gain s   [compute_control_input, controller.rs:117-135]
  *     y_t = C x_t; x_{t+1} = A x_t + B u_t                              [propagate_dynamics, controller.rs:101-115]

@@ -15,6 +15,8 @@ struct mpcx_ctx {
     size_t work_bytes;
     void *lu_work;       // augmented matrices of the blocked solver (systems beyond 64 unknowns)
     size_t lu_bytes;
+    void *aux;           // I - Ac dt of the general discretisation
+    size_t aux_bytes;
     void *stat_scratch;  // partial records of the stats reduction + one result record
     char err[512];
 };
@@ -142,6 +144,8 @@ int mpcx_create(mpcx_ctx **out, int device_id) {
     ctx->work_bytes = 0;
     ctx->lu_work = nullptr;
     ctx->lu_bytes = 0;
+    ctx->aux = nullptr;
+    ctx->aux_bytes = 0;
     ctx->stat_scratch = nullptr;
     ctx->err[0] = 0;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -165,6 +169,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->lu_work) (void)hipFree(ctx->lu_work);
+    if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->stat_scratch) (void)hipFree(ctx->stat_scratch);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -461,6 +466,139 @@ int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const d
     if (info) HIP_TRY(ctx, hipMemcpyAsync(info, dinfo, (size_t)d->batch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MPCX_OK;
+}
+
+int mpcx_c2d_backward_euler_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *Ac, const double *Bc, double dt,
+                                    double *A, double *B, int32_t *info, void *stream) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->batch == 0) return MPCX_OK;
+    if (!Ac || !Bc || !A || !B) return fail(ctx, MPCX_ERR_NULL, "Ac, Bc, A and B are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_c2d_lane(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, s);
+    if (rc == MPCX_ERR_UNSUPPORTED) {
+        const size_t need = (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n) * sizeof(double);
+        if (need > ctx->aux_bytes) {
+            if (ctx->aux) { HIP_TRY(ctx, hipFree(ctx->aux)); ctx->aux = nullptr; ctx->aux_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(&ctx->aux, need));
+            ctx->aux_bytes = need;
+        }
+        size_t wsd = 0;
+        rc = ensure_lu_work(ctx, d->n, d->n, d->batch, &wsd);
+        if (rc != MPCX_OK) return rc;
+        rc = launch_c2d_general(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, (double *)ctx->aux, (double *)ctx->lu_work, wsd, s);
+    }
+    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "c2d: n = %d is beyond what the solver holds on chip", d->n);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "c2d launch");
+    return MPCX_OK;
+}
+
+int mpcx_plants_f64_dev(mpcx_ctx *ctx, int kind, int64_t batch, int64_t interleave, const double *params, double dt,
+                        double *A, double *B, double *C, int32_t *info, void *stream) {
+    if (!ctx) return MPCX_ERR_NULL;
+    if (kind != MPCX_PLANT_DC_MOTOR && kind != MPCX_PLANT_TWO_MASS) return fail(ctx, MPCX_ERR_DIMS, "unknown plant kind %d", kind);
+    mpcx_dims d{};
+    d.n = kind == MPCX_PLANT_DC_MOTOR ? 2 : 4;
+    d.m = d.r = d.f = d.v = 1;
+    d.batch = batch;
+    d.interleave = interleave;
+    long long W = 1;
+    int rc = check_common(ctx, &d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (batch == 0) return MPCX_OK;
+    if (!params || !A || !B) return fail(ctx, MPCX_ERR_NULL, "params, A and B are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = launch_plants(kind, params, dt, A, B, C, info, batch, W, (hipStream_t)stream);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "plants launch");
+    return MPCX_OK;
+}
+
+namespace {
+// Generic host-pointer round trip: ni inputs up, run, no outputs + optional info down.
+struct HostIo {
+    const double *hin[8];
+    long long nin[8];
+    int ni;
+    double *hout[4];
+    long long nout[4];
+    int no;
+    int32_t *hinfo;
+    long long ninfo;
+    const double *din[8];
+    double *dout[4];
+    int32_t *dinfo;
+};
+int host_stage(mpcx_ctx *ctx, HostIo &io) {
+    size_t off_in[8], off_out[4], total = 0;
+    for (int i = 0; i < io.ni; ++i) { off_in[i] = total; if (io.hin[i]) total += align256((size_t)io.nin[i] * sizeof(double)); }
+    for (int i = 0; i < io.no; ++i) { off_out[i] = total; if (io.hout[i]) total += align256((size_t)io.nout[i] * sizeof(double)); }
+    const size_t off_info = total;
+    if (io.hinfo) total += align256((size_t)io.ninfo * sizeof(int32_t));
+    int rc = ensure_work(ctx, total ? total : 256);
+    if (rc != MPCX_OK) return rc;
+    char *base = (char *)ctx->work;
+    for (int i = 0; i < io.ni; ++i) {
+        io.din[i] = io.hin[i] ? (const double *)(base + off_in[i]) : nullptr;
+        if (io.hin[i] && io.nin[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync((void *)io.din[i], io.hin[i], (size_t)io.nin[i] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (int i = 0; i < io.no; ++i) io.dout[i] = io.hout[i] ? (double *)(base + off_out[i]) : nullptr;
+    io.dinfo = io.hinfo ? (int32_t *)(base + off_info) : nullptr;
+    return MPCX_OK;
+}
+int host_collect(mpcx_ctx *ctx, HostIo &io, int rc) {
+    if (rc != MPCX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    for (int i = 0; i < io.no; ++i)
+        if (io.hout[i] && io.nout[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(io.hout[i], io.dout[i], (size_t)io.nout[i] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (io.hinfo) HIP_TRY(ctx, hipMemcpyAsync(io.hinfo, io.dinfo, (size_t)io.ninfo * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCX_OK;
+}
+}  // namespace
+
+int mpcx_c2d_backward_euler_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *Ac, const double *Bc, double dt, double *A,
+                                double *B, int32_t *info) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->batch == 0) return MPCX_OK;
+    if (!Ac || !Bc || !A || !B) return fail(ctx, MPCX_ERR_NULL, "Ac, Bc, A and B are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long ea = mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n);
+    const long long eb = mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->m);
+    HostIo io{};
+    io.ni = 2; io.hin[0] = Ac; io.nin[0] = ea; io.hin[1] = Bc; io.nin[1] = eb;
+    io.no = 2; io.hout[0] = A; io.nout[0] = ea; io.hout[1] = B; io.nout[1] = eb;
+    io.hinfo = info; io.ninfo = d->batch;
+    rc = host_stage(ctx, io);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_c2d_backward_euler_f64_dev(ctx, d, io.din[0], io.din[1], dt, io.dout[0], io.dout[1], io.dinfo, (void *)ctx->stream);
+    return host_collect(ctx, io, rc);
+}
+
+int mpcx_plants_f64(mpcx_ctx *ctx, int kind, int64_t batch, int64_t interleave, const double *params, double dt, double *A,
+                    double *B, double *C, int32_t *info) {
+    if (!ctx) return MPCX_ERR_NULL;
+    if (kind != MPCX_PLANT_DC_MOTOR && kind != MPCX_PLANT_TWO_MASS) return fail(ctx, MPCX_ERR_DIMS, "unknown plant kind %d", kind);
+    if (batch < 0) return fail(ctx, MPCX_ERR_DIMS, "batch must be >= 0");
+    if (batch == 0) return MPCX_OK;
+    if (!params || !A || !B) return fail(ctx, MPCX_ERR_NULL, "params, A and B are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int n = kind == MPCX_PLANT_DC_MOTOR ? 2 : 4, np = kind == MPCX_PLANT_DC_MOTOR ? 5 : 6;
+    HostIo io{};
+    io.ni = 1; io.hin[0] = params; io.nin[0] = mpcx_array_elems(batch, interleave, np);
+    io.no = 3;
+    io.hout[0] = A; io.nout[0] = mpcx_array_elems(batch, interleave, n * n);
+    io.hout[1] = B; io.nout[1] = mpcx_array_elems(batch, interleave, n);
+    io.hout[2] = C; io.nout[2] = mpcx_array_elems(batch, interleave, n);
+    io.hinfo = info; io.ninfo = batch;
+    int rc = host_stage(ctx, io);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_plants_f64_dev(ctx, kind, batch, interleave, io.din[0], dt, io.dout[0], io.dout[1], io.dout[2], io.dinfo, (void *)ctx->stream);
+    return host_collect(ctx, io, rc);
 }
 
 int mpcx_closed_loop_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,

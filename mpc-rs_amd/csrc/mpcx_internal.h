@@ -47,6 +47,14 @@ int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *inf
                     double *ws, size_t ws_doubles, hipStream_t s);
 int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double *gain, int *info, long long batch,
                    long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s);
+int launch_solve_inplace(const double *H, double *X, int *info, long long batch, long long W, int nr, int nrhs, double *ws,
+                         size_t ws_doubles, hipStream_t s);
+int launch_c2d_lane(const double *Ac, const double *Bc, double dt, double *A, double *B, int *info, long long batch, long long W,
+                    int n, int m, hipStream_t s);
+int launch_c2d_general(const double *Ac, const double *Bc, double dt, double *A, double *B, int *info, long long batch,
+                       long long W, int n, int m, double *tmp, double *ws, size_t ws_doubles, hipStream_t s);
+int launch_plants(int kind, const double *params, double dt, double *A, double *B, double *C, int *info, long long batch,
+                  long long W, hipStream_t s);
 bool solve_fits_on_chip(int nr, int nrhs);
 size_t solve_large_ws_doubles(int nr, int nrhs);
 bool solve_large_supports(int nr);

@@ -323,6 +323,15 @@ int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *inf
     return launch_solve_large(H, fvec, nullptr, 0, u_seq, info, batch, W, vm, 1, 1, ws, ws_doubles, s);
 }
 
+// X = H^-1 R with R handed over in X (overwritten in place), any size the solvers take.
+int launch_solve_inplace(const double *H, double *X, int *info, long long batch, long long W, int nr, int nrhs, double *ws,
+                         size_t ws_doubles, hipStream_t s) {
+    SolveArgs a{H, X, X, info, batch, W, nr, nrhs, 0, nullptr, 0};  // every kernel reads R completely before it writes X
+    const int rc = launch_solve(a, s);
+    if (rc != MPCX_ERR_UNSUPPORTED) return rc;
+    return launch_solve_large(H, X, nullptr, 0, X, info, batch, W, nr, nrhs, 0, ws, ws_doubles, s);
+}
+
 int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double *gain, int *info, long long batch,
                    long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s) {
     const int nr = v * m, nrhs = f * r;

@@ -20,6 +20,7 @@ OK = 0
 ERR_NULL, ERR_DIMS, ERR_LAYOUT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SINGULAR = -1, -2, -3, -4, -5, -6
 WEIGHTS_BLOCK, WEIGHTS_DENSE = 0, 1
 HESSIAN_AUTO, HESSIAN_CONTRACT, HESSIAN_STRUCTURED = 0, 1, 2
+PLANT_DC_MOTOR, PLANT_TWO_MASS = 0, 1
 
 # every symbol include/mpcx.h declares
 EXPORTS = (
@@ -27,6 +28,7 @@ EXPORTS = (
     "mpcx_qp_build_f64", "mpcx_qp_build_f64_dev", "mpcx_rollout_f64", "mpcx_rollout_f64_dev",
     "mpcx_qp_solve_f64", "mpcx_qp_solve_f64_dev", "mpcx_qp_gain_f64", "mpcx_qp_gain_f64_dev",
     "mpcx_closed_loop_f64", "mpcx_closed_loop_f64_dev",
+    "mpcx_c2d_backward_euler_f64", "mpcx_c2d_backward_euler_f64_dev", "mpcx_plants_f64", "mpcx_plants_f64_dev",
     "mpcx_stats_f64_dev", "mpcx_stats_f64", "mpcx_relayout_f64_dev",
 )
 
@@ -98,6 +100,14 @@ def lib() -> C.CDLL:
     lb.mpcx_closed_loop_f64.restype = C.c_int
     lb.mpcx_closed_loop_f64_dev.argtypes = [vp, C.POINTER(Dims)] + [dp] * 10 + [vp]
     lb.mpcx_closed_loop_f64_dev.restype = C.c_int
+    lb.mpcx_c2d_backward_euler_f64.argtypes = [vp, C.POINTER(Dims), dp, dp, C.c_double, dp, dp, vp]
+    lb.mpcx_c2d_backward_euler_f64.restype = C.c_int
+    lb.mpcx_c2d_backward_euler_f64_dev.argtypes = [vp, C.POINTER(Dims), dp, dp, C.c_double, dp, dp, vp, vp]
+    lb.mpcx_c2d_backward_euler_f64_dev.restype = C.c_int
+    lb.mpcx_plants_f64.argtypes = [vp, C.c_int, i64, i64, dp, C.c_double, dp, dp, dp, vp]
+    lb.mpcx_plants_f64.restype = C.c_int
+    lb.mpcx_plants_f64_dev.argtypes = [vp, C.c_int, i64, i64, dp, C.c_double, dp, dp, dp, vp, vp]
+    lb.mpcx_plants_f64_dev.restype = C.c_int
     lb.mpcx_stats_f64_dev.argtypes = [vp, dp, i64, vp, vp]
     lb.mpcx_stats_f64_dev.restype = C.c_int
     lb.mpcx_stats_f64.argtypes = [vp, dp, i64, C.POINTER(Stats)]
@@ -227,6 +237,40 @@ class Context:
         info = np.full(max(batch, 1), -1, dtype=np.int32)
         self._check(self._lib.mpcx_qp_gain_f64(self._h, C.byref(d), _hp(hb), _hp(gb), _hp(qb), _hp(out), info.ctypes.data_as(C.c_void_p)))
         return L.unpack(out, batch, v * m, f * r, interleave), info[:batch]
+
+    def c2d_dev(self, dims: Dims, Ac, Bc, dt, A, B, info, stream=0):
+        self._check(self._lib.mpcx_c2d_backward_euler_f64_dev(self._h, C.byref(dims), Ac, Bc, dt, A, B, info, stream))
+
+    def plants_dev(self, kind, batch, interleave, params, dt, A, B, Cm, info, stream=0):
+        self._check(self._lib.mpcx_plants_f64_dev(self._h, kind, batch, interleave, params, dt, A, B, Cm, info, stream))
+
+    def c2d(self, Ac, Bc, dt, interleave=L.INTERLEAVE_AOS):
+        """Ac (batch, n, n), Bc (batch, n, m) -> A, B, info: backward Euler, A = (I - Ac dt)^-1, B = A Bc dt."""
+        Ac = np.asarray(Ac, dtype=np.float64)
+        Bc = np.asarray(Bc, dtype=np.float64)
+        batch, n, m = Ac.shape[0], Ac.shape[1], Bc.shape[2]
+        d = make_dims(n, m, 1, 1, 1, batch, 0, interleave)
+        a = np.full(max(L.array_elems(batch, interleave, n * n), 1), np.nan)
+        b = np.full(max(L.array_elems(batch, interleave, n * m), 1), np.nan)
+        info = np.full(max(batch, 1), -1, dtype=np.int32)
+        self._check(self._lib.mpcx_c2d_backward_euler_f64(self._h, C.byref(d), _hp(L.pack(Ac, interleave)), _hp(L.pack(Bc, interleave)),
+                                                          dt, _hp(a), _hp(b), info.ctypes.data_as(C.c_void_p)))
+        return L.unpack(a, batch, n, n, interleave), L.unpack(b, batch, n, m, interleave), info[:batch]
+
+    def plants(self, kind, params, dt, interleave=L.INTERLEAVE_AOS):
+        """params (batch, 5) for PLANT_DC_MOTOR (b, j, k, l, r) or (batch, 6) for PLANT_TWO_MASS (m1, m2, k1, k2, d1, d2)
+        -> A (batch, n, n), B (batch, n, 1), C (batch, 1, n), info."""
+        params = np.asarray(params, dtype=np.float64)
+        batch, n_par = params.shape
+        n = 2 if kind == PLANT_DC_MOTOR else 4
+        a = np.full(max(L.array_elems(batch, interleave, n * n), 1), np.nan)
+        b = np.full(max(L.array_elems(batch, interleave, n), 1), np.nan)
+        c = np.full(max(L.array_elems(batch, interleave, n), 1), np.nan)
+        info = np.full(max(batch, 1), -1, dtype=np.int32)
+        self._check(self._lib.mpcx_plants_f64(self._h, kind, batch, interleave, _hp(L.pack(params.reshape(batch, n_par, 1), interleave)),
+                                              dt, _hp(a), _hp(b), _hp(c), info.ctypes.data_as(C.c_void_p)))
+        return (L.unpack(a, batch, n, n, interleave), L.unpack(b, batch, n, 1, interleave),
+                L.unpack(c, batch, 1, n, interleave), info[:batch])
 
     def closed_loop_dev(self, dims: Dims, A, B, Cm, x0, Phi, gain, ref, X, U, Y, stream=0):
         self._check(self._lib.mpcx_closed_loop_f64_dev(self._h, C.byref(dims), A, B, Cm, x0, Phi, gain, ref, X, U, Y, stream))
