@@ -2,7 +2,7 @@
 """Benchmark of the batched MPC hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload two_mass|msd|quadrotor|long]
-                    [--op qp|rollout|solve|gain|loop] [--batch B_per_gpu] [--interleave W]
+                    [--op qp|rollout|solve|gain|loop|plants] [--batch B_per_gpu] [--interleave W]
 
 One "step" = one pass of the hot path over the rank's resident shard of synthetic plants: for --op qp one call of
 mpcx_qp_build_f64_dev storing Phi, Gamma, H and fvec for every instance; for --op rollout one call of
@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="two_mass", choices=sorted(DEFAULT_BATCH))
-    ap.add_argument("--op", default="qp", choices=["qp", "rollout", "solve", "gain", "loop"])
+    ap.add_argument("--op", default="qp", choices=["qp", "rollout", "solve", "gain", "loop", "plants"])
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's own)")
     ap.add_argument("--interleave", type=int, default=-1, help="-1: layout the kernels are native in")
     ap.add_argument("--hessian", type=int, default=0, help="0 auto, 1 dense contraction, 2 structured")
@@ -125,6 +125,21 @@ def main():
         unit_bytes = bytes_qp(n, m, r, f, v)
         metric, unit = "batched MPC QP builds/sec (Phi,Gamma,H,f)", "builds/s"
         check_buf = outs["H"]
+    elif args.op == "plants":
+        # Model::new for every instance: physical parameters -> discretised A, B, C (two-mass plant, n = 4)
+        assert args.workload == "two_mass", "--op plants is the two-mass parameter sweep"
+        rng = np.random.default_rng(1234 + rank)
+        prm = np.array([2.0, 2.0, 100.0, 200.0, 1.0, 5.0]) * (1.0 + 0.1 * rng.uniform(-1, 1, (count, 6)))
+        bufs["prm"] = to_dev(L.pack(prm.reshape(count, 6, 1), il))
+        outs = {"A": out(16), "B": out(4), "C": out(4)}
+        info = torch.zeros(count, dtype=torch.int32, device=dev)
+
+        def step():
+            ctx.plants_dev(ffi.PLANT_TWO_MASS, count, il, bufs["prm"].data_ptr(), 0.05, outs["A"].data_ptr(),
+                           outs["B"].data_ptr(), outs["C"].data_ptr(), info.data_ptr(), sp)
+        unit_bytes = 8 * (6 + 16 + 4 + 4) + 4
+        metric, unit = "batched plant constructions/sec (parameters -> A,B,C)", "plants/s"
+        check_buf = outs["A"]
     elif args.op in ("solve", "gain", "loop"):
         # operands come from a device-side build (and gain solve) outside the timed region
         qp = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
@@ -255,7 +270,7 @@ def main():
                                "kernel": "hessian_mfma_kernel", "flops_per_unit": flops_h(m, r, f, v),
                                "dense_flops_per_unit": 2 * f * r * (v * m) ** 2, "step_ms_all_kernels": kernel_ms,
                                "hbm_frac_whole_step": achieved / HBM_PEAK}
-        if args.op in ("solve", "gain", "loop"):
+        if args.op in ("solve", "gain", "loop", "plants"):
             res["check"]["singular_instances"] = int((info != 0).sum().item())
         if world == 1 and not args.no_cpu_baseline and args.op in ("qp", "rollout"):
             res["cpu_baseline"] = _cpu_baseline(args, d, n, m, r, f, v, T, unit)

@@ -12,6 +12,9 @@
  * restated from its published algorithm: column-major storage, left-associative products,
  * k-ascending mul-add accumulation, closed-form inverses for dimension <= 4 and LU with
  * partial pivoting above.  Last-bit agreement with a Rust build is not claimed.
+ * The only outputs the reference itself holds are its two charts; the curves read out of them
+ * (tests/golden/*_png_trace.json) pin this restatement at chart resolution (one pixel: about
+ * 2e-4 of the step response, 2e-3 of the controlled output) and no further.
  *
  * All matrices are dense f64, column-major (element (i,j) of an R x C matrix at [j*R + i]),
  * which is what nalgebra's DMatrix::as_slice() yields.
