@@ -16,8 +16,8 @@
 // Loads and stores of one wave retire through a single in-order counter, so a wave that has stores in flight
 // waits for all of them before a later load returns.  The four compute waves therefore never load from global
 // memory once their first store is out: everything they need is in LDS, and the shared weight W3 (dense,
-// (v m)^2, far larger than LDS) is streamed column block by column block into an LDS ring by a fifth wave that
-// never stores.
+// (v m)^2, far larger than LDS) is streamed column block by column block into an LDS ring by three more waves
+// that never store and take the blocks in turn, so that every fetch has two sweep steps to arrive.
 //
 // Reference math: src/control/controller.rs:32-44 (Phi), :46-90 (Gamma), :92-93 (H), :96 and :125-127 (fvec).
 #include "mpcx_internal.h"
@@ -26,7 +26,8 @@ namespace mpcx {
 namespace {
 
 constexpr int kCompute = 256;            // threads that compute and store
-constexpr int kWgBlock = kCompute + 64;  // + one loader wave
+constexpr int kLoaders = 3;               // loader waves: each fetches every kLoaders-th column block of W3
+constexpr int kWgBlock = kCompute + 64 * kLoaders;
 constexpr int kCoef = 16;                // recurrence coefficients a thread keeps in registers (n <= kCoef)
 
 struct WgLds {
@@ -82,10 +83,13 @@ __device__ inline double h_direct(const double *sG, const double *sS, const doub
 // The loader wave's W3 pipeline.  A column block of W3 (cnt doubles, contiguous) is fetched into registers during
 // one sweep step and written to its LDS ring slot during the next, so the fetch latency hides behind a whole step.
 // Up to kPreDoubles doubles per lane are held; larger blocks are fetched in place (latency exposed).
-constexpr int kPre = 16;  // register slots per lane, one or two doubles each
+constexpr int kPre = 13;  // register slots per lane, one or two doubles each
 struct W3Pipe {
     double2 r[kPre];
 };
+// Loads are unconditional (an index past the block is clamped to its last element and the value dropped at commit):
+// a load guarded by a per-lane branch makes the compiler wait for it before issuing the next one, which serialises
+// the fetch and keeps the wave from reaching the step's barrier.
 __device__ __forceinline__ void w3_fetch(W3Pipe &pp, const double *src, int cnt, int lane, bool wide) {
     if (wide) {
         const double2 *s2 = (const double2 *)src;
@@ -93,13 +97,13 @@ __device__ __forceinline__ void w3_fetch(W3Pipe &pp, const double *src, int cnt,
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
             const int e = lane + u * 64;
-            if (e < n2) pp.r[u] = s2[e];
+            if (u * 64 < n2) pp.r[u] = s2[e < n2 ? e : n2 - 1];  // wave-uniform guard
         }
     } else {
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
             const int e = lane + u * 64;
-            if (e < cnt) pp.r[u].x = src[e];
+            if (u * 64 < cnt) pp.r[u].x = src[e < cnt ? e : cnt - 1];
         }
     }
 }
@@ -127,8 +131,8 @@ template <int HM, int HR, int ITEMS>
 __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
-    const bool loader = tid >= kCompute;  // wave-uniform: the fifth wave
-    const int ltid = tid - kCompute;
+    const bool loader = tid >= kCompute;  // wave-uniform: the waves after the four compute waves
+    const int ltid = (tid - kCompute) & 63, lw = (tid - kCompute) >> 6;  // lane and index of the loader wave
     const long long b = blockIdx.x;
     const int n = p.n, m = HM ? HM : p.m, r = HR ? HR : p.r, f = p.f, v = p.v;
     const int FR = f * r, VM = v * m, nl = f - v + 1;
@@ -294,8 +298,15 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     }
     lds_barrier();
 
-    // ---- Gamma: column (k, c) = [zeros(k r) ; Markov vector c] (or the cumulated vector for k = v-1) ----
-    if (p.Gamma && !loader) {
+    // ---- Gamma: column (k, c) = [zeros(k r) ; Markov vector c] (or the cumulated vector for k = v-1).
+    //      A pure store stream from LDS (G and S stay valid to the end of the kernel), so it can run before or after
+    //      the H sweep.  Workgroups that share a CU run the same phases for the same time and would stay in lockstep,
+    //      all storing Gamma at once and all sweeping at once; every other resident workgroup therefore writes Gamma
+    //      last, so that one workgroup's store stream overlaps the other's sweep.
+    //      Only where Gamma is the bulk of the bytes (f r >= 2 v m): with H as large as Gamma the sweep is a store
+    //      stream itself, and workgroups sweeping in step share their W3 blocks in L2. ----
+    const bool gamma_last = p.Gamma && p.H && FR >= 2 * VM && (blockIdx.x & 1);
+    auto write_gamma = [&]() {
         double *gG = p.Gamma + b * (long long)FR * VM;
         const int wave = tid >> 6, lane = tid & 63, nwaves = kCompute >> 6;
         for (int col = wave; col < VM; col += nwaves) {
@@ -305,7 +316,8 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             double *dst = gG + (long long)col * FR;
             for (int row = lane; row < FR; row += 64) dst[row] = (row < shift) ? 0.0 : src[row - shift];
         }
-    }
+    };
+    if (p.Gamma && !loader && !gamma_last) write_gamma();
 
     // ---- fvec[col] = sum_rows Gamma[row][col] Z[row] ----
     if (p.fvec && !loader) {
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         if (loader) {
             const double *src = p.W3 + (long long)(v - 1) * wcnt;
             double *dst = sW3 + ((v - 1) & 1) * wcnt;
-            for (int e = ltid; e < wcnt; e += 64) dst[e] = src[e];
+            for (int e = tid - kCompute; e < wcnt; e += 64 * kLoaders) dst[e] = src[e];
         }
         const int bsz = m * m, tsz = v * bsz;
         const bool held = nl > 1;
@@ -377,14 +389,22 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             // Two loops with the same number of barriers: the loader wave's and the compute waves'.  Keeping them
             // apart keeps the loader's fetch registers and the compute waves' G blocks out of each other's live ranges.
             if (loader) {
+                // Block k belongs to loader wave k % kLoaders, which fetches it into registers kLoaders steps before
+                // the step that needs it and commits it to the ring one step before: a fetch has kLoaders - 1 whole
+                // steps to complete, and no wave waits on a load it has just issued.
                 W3Pipe pipe;
-                if (piped && v >= 2) w3_fetch(pipe, p.W3 + (long long)(v - 2) * wcnt, wcnt, ltid, wide);
+                {
+                    int k0 = v - 2;  // first block this wave commits: the largest k <= v-2 with k % kLoaders == lw
+                    while (k0 >= 0 && (k0 % kLoaders) != lw) --k0;
+                    if (piped && k0 >= 0) w3_fetch(pipe, p.W3 + (long long)k0 * wcnt, wcnt, ltid, wide);
+                }
                 for (int bb = v - 1; bb >= 0; --bb) {
-                    if (bb > 0) {  // block bb-1 into the slot the next step reads; then fetch block bb-2 ahead
+                    if (bb > 0 && ((bb - 1) % kLoaders) == lw) {  // block bb-1 into the slot the next step reads
                         double *dst = sW3 + ((bb - 1) & 1) * wcnt;
                         if (piped) {
                             w3_commit(pipe, dst, wcnt, ltid, wide);
-                            if (bb > 1) w3_fetch(pipe, p.W3 + (long long)(bb - 2) * wcnt, wcnt, ltid, wide);
+                            if (bb - 1 - kLoaders >= 0)
+                                w3_fetch(pipe, p.W3 + (long long)(bb - 1 - kLoaders) * wcnt, wcnt, ltid, wide);
                         } else {
                             const double *src = p.W3 + (long long)(bb - 1) * wcnt;
                             for (int e = ltid; e < wcnt; e += 64) dst[e] = src[e];
@@ -452,14 +472,22 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             // Two loops with the same number of barriers: the loader wave's and the compute waves'.  Keeping them
             // apart keeps the loader's fetch registers and the compute waves' G blocks out of each other's live ranges.
             if (loader) {
+                // Block k belongs to loader wave k % kLoaders, which fetches it into registers kLoaders steps before
+                // the step that needs it and commits it to the ring one step before: a fetch has kLoaders - 1 whole
+                // steps to complete, and no wave waits on a load it has just issued.
                 W3Pipe pipe;
-                if (piped && v >= 2) w3_fetch(pipe, p.W3 + (long long)(v - 2) * wcnt, wcnt, ltid, wide);
+                {
+                    int k0 = v - 2;  // first block this wave commits: the largest k <= v-2 with k % kLoaders == lw
+                    while (k0 >= 0 && (k0 % kLoaders) != lw) --k0;
+                    if (piped && k0 >= 0) w3_fetch(pipe, p.W3 + (long long)k0 * wcnt, wcnt, ltid, wide);
+                }
                 for (int bb = v - 1; bb >= 0; --bb) {
-                    if (bb > 0) {  // block bb-1 into the slot the next step reads; then fetch block bb-2 ahead
+                    if (bb > 0 && ((bb - 1) % kLoaders) == lw) {  // block bb-1 into the slot the next step reads
                         double *dst = sW3 + ((bb - 1) & 1) * wcnt;
                         if (piped) {
                             w3_commit(pipe, dst, wcnt, ltid, wide);
-                            if (bb > 1) w3_fetch(pipe, p.W3 + (long long)(bb - 2) * wcnt, wcnt, ltid, wide);
+                            if (bb - 1 - kLoaders >= 0)
+                                w3_fetch(pipe, p.W3 + (long long)(bb - 1 - kLoaders) * wcnt, wcnt, ltid, wide);
                         } else {
                             const double *src = p.W3 + (long long)(bb - 1) * wcnt;
                             for (int e = ltid; e < wcnt; e += 64) dst[e] = src[e];
@@ -500,6 +528,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             }
         }
     }
+    if (gamma_last && !loader) write_gamma();
 }
 
 template <int HM, int HR, int ITEMS>
