@@ -40,6 +40,18 @@ __global__ void tiled8(double *p, size_t batch, int P, int TW) {
     for (int e = 0; e < P; ++e) { *q = (double)e; q += TW; }
 }
 
+// non-temporal variants (stores marked streaming: no intent to re-read)
+__global__ void fill16_nt(double2 *p, size_t n2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, s = (size_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += s) { __builtin_nontemporal_store(1.0, &p[i].x); __builtin_nontemporal_store(2.0, &p[i].y); }
+}
+__global__ void tiled8_nt(double *p, size_t batch, int P, int TW) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double *q = p + (b / TW) * (size_t)P * TW + (b % TW);
+    for (int e = 0; e < P; ++e) { __builtin_nontemporal_store((double)e, q); q += TW; }
+}
+
 template <class F> float time_it(F f, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); f(); CK(hipDeviceSynchronize());
@@ -65,7 +77,11 @@ int main() {
         for (int tw : {64, 256, 4096}) {
             ms = time_it([&] { tiled8<<<batch / blk, blk>>>(p, batch, P, tw); }, 10);
             printf("tiled8 TW %4d block %3d : %7.1f GB/s\n", tw, blk, gb / ms * 1e3);
+            ms = time_it([&] { tiled8_nt<<<batch / blk, blk>>>(p, batch, P, tw); }, 10);
+            printf("tiled8_nt TW %4d block %3d : %7.1f GB/s\n", tw, blk, gb / ms * 1e3);
         }
+        ms = time_it([&] { fill16_nt<<<8192, blk>>>((double2 *)p, n / 2); }, 10);
+        printf("fill16_nt grid   8192 block %3d : %7.1f GB/s\n", blk, gb / ms * 1e3);
     }
     return 0;
 }
