@@ -301,6 +301,7 @@ __global__ __launch_bounds__(kGroupThreads) void closed_loop_group_kernel(LoopAr
                     const int c = c0 + g * kGroupThreads;
                     cc[g] = c < FR ? c : FR - 1;  // clamped: surplus rows are computed and dropped
                 }
+#pragma unroll 4
                 for (int j = 0; j < n; ++j) {
                     const double xj = xc[j];
 #pragma unroll
@@ -323,12 +324,16 @@ __global__ __launch_bounds__(kGroupThreads) void closed_loop_group_kernel(LoopAr
                 }
             }
             if (m <= 4) {
+                // the four sums go down the tree together: four permutes in flight per level instead of one
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    double v = uacc[k];
-                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                    if (lane == 0) sPart[wv * 4 + k] = v;
+                for (int off = 32; off > 0; off >>= 1) {
+                    double o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = __shfl_xor(uacc[k], off);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) uacc[k] += o[k];
                 }
+                if (lane < 4) sPart[wv * 4 + lane] = lane == 0 ? uacc[0] : lane == 1 ? uacc[1] : lane == 2 ? uacc[2] : uacc[3];
                 lds_barrier();
                 if (tid < m) {
                     double v = 0.0;
@@ -349,8 +354,10 @@ __global__ __launch_bounds__(kGroupThreads) void closed_loop_group_kernel(LoopAr
             lds_barrier();
             if (tid < n) {
                 double sacc = 0.0;
+#pragma unroll 4
                 for (int j = 0; j < n; ++j) sacc += sA[j * n + tid] * xc[j];
                 double qv = 0.0;
+#pragma unroll 4
                 for (int k = 0; k < m; ++k) qv += sB[k * n + tid] * su[k];
                 sacc += qv;
                 xn[tid] = sacc;
@@ -358,6 +365,7 @@ __global__ __launch_bounds__(kGroupThreads) void closed_loop_group_kernel(LoopAr
             } else if (tid >= kWave && tid < kWave + r) {  // outputs on the second wavefront
                 const int a = tid - kWave;
                 double y = 0.0;
+#pragma unroll 4
                 for (int j = 0; j < n; ++j) y += sC[j * r + a] * xc[j];
                 out[n + m + a] = y;
             }
