@@ -583,3 +583,146 @@ int orc_rollout_batch(int64_t batch, int n, int m, int r, int64_t T, const doubl
     (void)threads;
     return used;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * A CPU implementation one would write for speed, for bench.py's second baseline line: same outputs as
+ * orc_qp_build_batch with W4 = blockdiag(Q), but Markov blocks and Phi from O(f) recurrences (w <- A w,
+ * P <- P A) instead of the reference's re-multiplied powers, H through the block-Toeplitz recurrence
+ * H[a][b] = H[a+1][b+1] + G_(f-1-a)^T Q G_(f-1-b) (f = v) or plain Gram sums (f > v), one scratch
+ * buffer per thread.  Not a restatement of the reference's loop structure, hence not the parity oracle:
+ * tests compare it against orc_qp_build_batch.
+ * ------------------------------------------------------------------------------------------------- */
+int orc_qp_build_batch_fast(int64_t batch, int n, int m, int r, int f, int v, const double *A, const double *B,
+                            const double *C, const double *W3, const double *Q, const double *x0, const double *ref,
+                            double *Phi, double *Gamma, double *H, double *fvec, int threads) {
+    const size_t eA = (size_t)n * n, eB = (size_t)n * m, eC = (size_t)r * n;
+    const int fr = f * r, vm = v * m, nl = f - v + 1;
+    const size_t ePhi = (size_t)fr * n, eG = (size_t)fr * vm, eH = (size_t)vm * vm;
+    int used = 1;
+#ifdef _OPENMP
+    if (threads > 1) used = threads;
+#pragma omp parallel num_threads(used)
+#endif
+    {
+        /* per thread: G (fr x m), QG (fr x m), S (nl*r x m), QS, W (n x m) x2, P (r x n) x2, s (fr), z (fr), gam (fr x vm) */
+        double *buf = (double *)malloc(sizeof(double) * ((size_t)4 * fr * m + 2 * n * m + 2 * r * n + 2 * fr + eG + 16));
+        double *G = buf, *QG = G + (size_t)fr * m, *S = QG + (size_t)fr * m, *QS = S + (size_t)fr * m;
+        double *W0 = QS + (size_t)fr * m, *W1 = W0 + n * m, *P0 = W1 + n * m, *P1 = P0 + r * n;
+        double *sv = P1 + r * n, *z = sv + fr, *gam = z + fr;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int64_t b = 0; b < batch; ++b) {
+            const double *a = A + (size_t)b * eA, *bm = B + (size_t)b * eB, *c = C + (size_t)b * eC;
+            double *phi = Phi ? Phi + (size_t)b * ePhi : NULL;
+            double *gout = Gamma ? Gamma + (size_t)b * eG : gam;
+            /* recurrences: G_k = C W_k (W_0 = B), Phi_k = P_k A (P_0 = C) */
+            memcpy(W0, bm, sizeof(double) * n * m);
+            memcpy(P0, c, sizeof(double) * r * n);
+            double *w = W0, *wn = W1, *pk = P0, *pn = P1;
+            for (int k = 0; k < f; ++k) {
+                for (int j = 0; j < m; ++j)
+                    for (int i = 0; i < r; ++i) {
+                        double acc = 0.0;
+                        for (int q = 0; q < n; ++q) acc += c[(size_t)q * r + i] * w[(size_t)j * n + q];
+                        G[(size_t)j * fr + k * r + i] = acc;
+                    }
+                for (int j = 0; j < m; ++j)
+                    for (int i = 0; i < n; ++i) {
+                        double acc = 0.0;
+                        for (int q = 0; q < n; ++q) acc += a[(size_t)q * n + i] * w[(size_t)j * n + q];
+                        wn[(size_t)j * n + i] = acc;
+                    }
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < r; ++i) {
+                        double acc = 0.0;
+                        for (int q = 0; q < n; ++q) acc += pk[(size_t)q * r + i] * a[(size_t)j * n + q];
+                        pn[(size_t)j * r + i] = acc;
+                        if (phi) phi[(size_t)j * fr + k * r + i] = acc;
+                    }
+                if (fvec) {
+                    for (int i = 0; i < r; ++i) {
+                        double acc = 0.0;
+                        for (int q = 0; q < n; ++q) acc += pn[(size_t)q * r + i] * x0[(size_t)b * n + q];
+                        sv[k * r + i] = acc - ref[(size_t)b * fr + k * r + i];
+                    }
+                }
+                double *t = w; w = wn; wn = t;
+                t = pk; pk = pn; pn = t;
+            }
+            /* S_j, Q G, Q S, z = Q s */
+            for (int j = 0; j < m; ++j)
+                for (int i = 0; i < r; ++i) {
+                    double run = 0.0;
+                    for (int k = 0; k < nl; ++k) { run += G[(size_t)j * fr + k * r + i]; S[(size_t)j * fr + k * r + i] = run; }
+                }
+            for (int j = 0; j < m; ++j)
+                for (int k = 0; k < f; ++k)
+                    for (int i = 0; i < r; ++i) {
+                        double acc = 0.0, acs = 0.0;
+                        for (int q = 0; q < r; ++q) {
+                            acc += Q[(size_t)q * r + i] * G[(size_t)j * fr + k * r + q];
+                            if (k < nl) acs += Q[(size_t)q * r + i] * S[(size_t)j * fr + k * r + q];
+                        }
+                        QG[(size_t)j * fr + k * r + i] = acc;
+                        if (k < nl) QS[(size_t)j * fr + k * r + i] = acs;
+                    }
+            if (fvec)
+                for (int k = 0; k < f; ++k)
+                    for (int i = 0; i < r; ++i) {
+                        double acc = 0.0;
+                        for (int q = 0; q < r; ++q) acc += Q[(size_t)q * r + i] * sv[k * r + q];
+                        z[k * r + i] = acc;
+                    }
+            /* Gamma columns: shifted Markov vectors; the last block column holds S when f > v */
+            for (int kb = 0; kb < v; ++kb)
+                for (int j = 0; j < m; ++j) {
+                    double *col = gout + (size_t)(kb * m + j) * fr;
+                    const double *src = (kb == v - 1) ? S + (size_t)j * fr : G + (size_t)j * fr;
+                    const int shift = kb * r;
+                    memset(col, 0, sizeof(double) * shift);
+                    memcpy(col + shift, src, sizeof(double) * (fr - shift));
+                }
+            if (fvec)
+                for (int col = 0; col < vm; ++col) {
+                    const double *gc = gout + (size_t)col * fr;
+                    const int shift = (col / m) * r;
+                    double acc = 0.0;
+                    for (int t = shift; t < fr; ++t) acc += gc[t] * z[t];
+                    fvec[(size_t)b * vm + col] = acc;
+                }
+            if (H) {
+                double *h = H + (size_t)b * eH;
+                /* column blocks from right to left; Toeplitz recurrence away from the last two block rows / columns */
+                for (int bb = v - 1; bb >= 0; --bb)
+                    for (int j = 0; j < m; ++j)
+                        for (int aa = v - 1; aa >= 0; --aa)
+                            for (int i = 0; i < m; ++i) {
+                                double acc;
+                                const int rec = (nl == 1) ? (aa < v - 1 && bb < v - 1) : (aa < v - 2 && bb < v - 2);
+                                if (rec) {
+                                    acc = h[(size_t)((bb + 1) * m + j) * vm + (aa + 1) * m + i] -
+                                          W3[(size_t)((bb + 1) * m + j) * vm + (aa + 1) * m + i];
+                                    const double *ga = G + (size_t)i * fr + (size_t)(f - 1 - aa) * r;
+                                    const double *qb = QG + (size_t)j * fr + (size_t)(f - 1 - bb) * r;
+                                    for (int q = 0; q < r; ++q) acc += ga[q] * qb[q];
+                                } else {
+                                    acc = 0.0;
+                                    const int i0 = aa > bb ? aa : bb;
+                                    for (int i2 = i0; i2 < f; ++i2) {
+                                        const double *ga = (aa == v - 1) ? S + (size_t)i * fr + (size_t)(i2 - (v - 1)) * r
+                                                                         : G + (size_t)i * fr + (size_t)(i2 - aa) * r;
+                                        const double *qb = (bb == v - 1) ? QS + (size_t)j * fr + (size_t)(i2 - (v - 1)) * r
+                                                                         : QG + (size_t)j * fr + (size_t)(i2 - bb) * r;
+                                        for (int q = 0; q < r; ++q) acc += ga[q] * qb[q];
+                                    }
+                                }
+                                h[(size_t)(bb * m + j) * vm + aa * m + i] = acc + W3[(size_t)(bb * m + j) * vm + aa * m + i];
+                            }
+            }
+        }
+        free(buf);
+    }
+    (void)threads;
+    return used;
+}

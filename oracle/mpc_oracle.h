@@ -13,7 +13,7 @@
  * k-ascending mul-add accumulation, closed-form inverses for dimension <= 4 and LU with
  * partial pivoting above.  Last-bit agreement with a Rust build is not claimed.
  * The only outputs the reference itself holds are its two charts; the curves read out of them
- * (tests/golden/*_png_trace.json) pin this restatement at chart resolution (one pixel: about
+ * (the two _png_trace.json files under tests/golden) pin this restatement at chart resolution (one pixel: about
  * 2e-4 of the step response, 2e-3 of the controlled output) and no further.
  *
  * All matrices are dense f64, column-major (element (i,j) of an R x C matrix at [j*R + i]),
@@ -103,4 +103,11 @@ int orc_rollout_batch(int64_t batch, int n, int m, int r, int64_t T, const doubl
 #ifdef __cplusplus
 }
 #endif
+/* A CPU implementation written for speed (O(f) recurrences, block-diagonal W4 given as its r x r block Q, one scratch
+ * buffer per thread) with the same outputs as orc_qp_build_batch: the second, "optimised" CPU baseline of bench.py.
+ * It does not keep the reference's loop structure and is therefore not the parity oracle. */
+int orc_qp_build_batch_fast(int64_t batch, int n, int m, int r, int f, int v, const double *A, const double *B,
+                            const double *C, const double *W3, const double *Q, const double *x0, const double *ref,
+                            double *Phi, double *Gamma, double *H, double *fvec, int threads);
+
 #endif

@@ -55,6 +55,8 @@ def lib(variant: str = "") -> C.CDLL:
     L.orc_try_inverse.restype = i
     L.orc_qp_build_batch.argtypes = [i64, i, i, i, i, i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, i]
     L.orc_qp_build_batch.restype = i
+    L.orc_qp_build_batch_fast.argtypes = [i64, i, i, i, i, i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, i]
+    L.orc_qp_build_batch_fast.restype = i
     L.orc_rollout_batch.argtypes = [i64, i, i, i, i64, _P, _P, _P, _P, _P, i, _P, _P, i]
     L.orc_rollout_batch.restype = i
     _LIBS[variant] = L
@@ -176,7 +178,7 @@ def try_inverse(a, variant=""):
 
 
 def qp_build_batch(A, B, Cm, W3, W4, x0, ref, f, v, threads=1, variant="", want=("Phi", "Gamma", "H", "fvec"),
-                   timing=None):
+                   timing=None, fast=False):
     """Instance-major batch: A (batch, n, n) etc. as (row, col) arrays per instance; W3/W4 shared.
 
     Returns dict of (batch, rows, cols) arrays and the thread count used.  When `timing` is a dict, the wall
@@ -197,7 +199,11 @@ def qp_build_batch(A, B, Cm, W3, W4, x0, ref, f, v, threads=1, variant="", want=
         "H": np.zeros(batch * v * m * v * m) if "H" in want else None,
         "fvec": np.zeros(batch * v * m) if "fvec" in want else None,
     }
-    fn = lib(variant).orc_qp_build_batch
+    if fast:  # the speed-oriented CPU implementation; takes the r x r block of the (block-diagonal) W4
+        fn = lib(variant).orc_qp_build_batch_fast
+        w4_ = _cm(np.asarray(W4, dtype=np.float64)[:r, :r])
+    else:
+        fn = lib(variant).orc_qp_build_batch
     t0 = _time.perf_counter()
     used = fn(batch, n, m, r, f, v, _p(a_), _p(b_), _p(c_), _p(w3_), _p(w4_), _p(x_), _p(r_), _p(bufs["Phi"]),
               _p(bufs["Gamma"]), _p(bufs["H"]), _p(bufs["fvec"]), threads)
