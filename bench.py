@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's own)")
     ap.add_argument("--interleave", type=int, default=-1, help="-1: layout the kernels are native in")
     ap.add_argument("--hessian", type=int, default=0, help="0 auto, 1 dense contraction, 2 structured")
+    ap.add_argument("--gather", default="fvec", choices=["none", "fvec", "H", "check"],
+                    help="N > 1: result array gathered to rank 0 over RCCL after the timed region (reported apart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances timed on the CPU (default: ~15 s worth)")
     args = ap.parse_args()
@@ -81,8 +83,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knob (not used by the driver): MPCX_BENCH_REHEARSE=1 runs all ranks on device 0 over gloo, so the
+    # N > 1 code path can be exercised on a one-GPU box.  The real run is one rank per GPU over RCCL ("nccl").
+    rehearse = os.environ.get("MPCX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = ffi.Context(local_rank)
@@ -244,6 +254,29 @@ def main():
     elapsed = float(tmax.item())
     merged = shard.merge_stats([shard.stats_from_words(x.cpu().numpy()) for x in recs])
 
+    # ---- optional gather of a result array to rank 0 (RCCL over xGMI); never part of the timed region ----
+    gathered = None
+    if world > 1 and args.gather != "none":
+        src = outs.get(args.gather) if args.gather != "check" else check_buf
+        if src is None:
+            src = check_buf
+        try:
+            dst = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            dist.gather(src, dst, dst=0)
+            torch.cuda.synchronize()
+            gms = (time.perf_counter() - g0) * 1e3
+            nbytes = src.numel() * src.element_size()
+            gathered = {"array": args.gather, "bytes_per_rank": nbytes, "ms": gms,
+                        "GB_per_s_into_rank0": nbytes * (world - 1) / gms / 1e6}
+            if rank == 0:  # rank 0's own shard must come back unchanged
+                gathered["self_check"] = bool(torch.equal(dst[0], src))
+            del dst
+        except Exception as exc:  # the gather is a report, not the benchmark: never lose the line over it
+            gathered = {"array": args.gather, "error": str(exc)[:200]}
+
     if rank == 0:
         total = per_gpu * world
         value = total * args.steps / elapsed
@@ -261,6 +294,8 @@ def main():
             "check": {"elements": merged["count"], "non_finite": merged["non_finite"], "sum_sq": merged["sum_sq"],
                       "checksum": "%016x" % merged["checksum"]},
         }
+        if gathered is not None:
+            res["gather"] = gathered
         if mfma_ms is not None:
             # the contraction kernel against the FP64 matrix-core peak, in algorithmic flops (symmetric count,
             # block-diagonal weight); the dense count 2 (f r)(v m)^2 is printed beside it
