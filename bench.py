@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--op", default="qp", choices=["qp", "rollout", "solve", "gain", "loop", "plants"])
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's own)")
     ap.add_argument("--interleave", type=int, default=-1, help="-1: layout the kernels are native in")
+    ap.add_argument("--f", type=int, default=0, help="prediction horizon override (default: the workload's)")
+    ap.add_argument("--v", type=int, default=0, help="control horizon override (default: the workload's, or --f)")
     ap.add_argument("--hessian", type=int, default=0, help="0 auto, 1 dense contraction, 2 structured")
     ap.add_argument("--gather", default="fvec", choices=["none", "fvec", "H", "check"],
                     help="N > 1: result array gathered to rank 0 over RCCL after the timed region (reported apart)")
@@ -99,6 +101,9 @@ def main():
 
     wl = synth.WORKLOADS[args.workload]
     n, m, r, f, v, T = wl["n"], wl["m"], wl["r"], wl["f"], wl["v"], wl["T"]
+    if args.f:
+        f = args.f
+        v = args.v or f
     per_gpu = args.batch or DEFAULT_BATCH[args.workload]
     lane_native = (m <= 2 and r <= 2 and n <= 6)
     # lane kernels: batch tiled in groups of 4096 instances (measured fastest); workgroup kernels: instance-major
@@ -110,7 +115,7 @@ def main():
     def to_dev(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
-    d = synth.make_batch(args.workload, count, start=start)
+    d = synth.make_batch(args.workload, count, start=start, f=f, v=v)
     bufs = {k: to_dev(L.pack(d[k], il)) for k in ("A", "B", "C")}
     bufs["x0"] = to_dev(L.pack(d["x0"].reshape(count, n, 1), il))
     bufs["ref"] = to_dev(L.pack(d["ref"].reshape(count, f * r, 1), il))
@@ -285,7 +290,7 @@ def main():
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: n={n} m={m} r={r} f=v={f}" + (f" T={T}" if args.op in ("rollout", "loop") else ""),
+            "config": {"workload": f"{args.workload}: n={n} m={m} r={r} " + (f"f=v={f}" if f == v else f"f={f} v={v}") + (f" T={T}" if args.op in ("rollout", "loop") else ""),
                        "op": args.op, "batch_per_gpu": per_gpu, "global_batch": total, "interleave": il,
                        "parallelism": f"batch-sharded x{world}", "hessian_algo": args.hessian},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
