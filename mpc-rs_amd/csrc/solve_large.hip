@@ -44,8 +44,10 @@ struct PackArgs {
     int nr, nrhs, r, nrp, ncp;
 };
 
-__global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p) {
-    const long long per = (long long)p.nrp * p.ncp;
+// Elementwise part: the H block (with its identity padding) and, when the right-hand side is given as such (Q == nullptr),
+// the right-hand side columns.  `ncols` = nrp or ncp accordingly.  Lanes run along the rows of a column on both sides.
+__global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p, int ncols) {
+    const long long per = (long long)p.nrp * ncols;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.count * per) return;
     const long long li = idx / per, e = idx - li * per;
@@ -57,19 +59,42 @@ __global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p) {
                                        : (row == col ? 1.0 : 0.0);
     } else {
         const int c = col - p.nrp;
-        v = 0.0;
-        if (row < p.nr && c < p.nrhs) {
-            const long long ER = (long long)p.nr * p.nrhs;
-            if (p.Q == nullptr) {
-                v = p.R[elem_index(b, (long long)c * p.nr + row, ER, p.W)];
-            } else {  // sum_a Gamma[blk r + a][row] Q[a][a2], c = blk r + a2   (controller.rs:96, M^T W4)
-                const int blk = c / p.r, a2 = c - blk * p.r;
-                for (int a = 0; a < p.r; ++a)
-                    v += p.R[elem_index(b, (long long)row * p.nrhs + blk * p.r + a, ER, p.W)] * p.Q[a2 * p.r + a];
-            }
-        }
+        v = (row < p.nr && c < p.nrhs) ? p.R[elem_index(b, (long long)c * p.nr + row, (long long)p.nr * p.nrhs, p.W)] : 0.0;
     }
-    p.ws[idx] = v;
+    p.ws[li * (long long)p.nrp * p.ncp + e] = v;
+}
+
+// Right-hand side Gamma^T blockdiag(Q) (controller.rs:96, M^T W4): column c = blk r + a2, row k is
+// sum_a Gamma[blk r + a][k] Q[a][a2].  Gamma is (f r) x (v m) column-major, so its rows are the contiguous direction
+// while the workspace wants k contiguous: a workgroup moves a tile of 16 unknowns x TC rows of Gamma (TC a multiple of r)
+// through LDS, reading along Gamma's rows and writing along the workspace's.
+constexpr int kTileK = 16, kTileCMax = 64;
+__global__ __launch_bounds__(256) void lu_pack_gamma_kernel(PackArgs p, int TC, int CT, int KT) {
+    __shared__ double tile[kTileK][kTileCMax + 1];
+    long long t = blockIdx.x;
+    const int kt = (int)(t % KT);
+    t /= KT;
+    const int ct = (int)(t % CT);
+    const long long li = t / CT, b = p.first + li;
+    const int k0 = kt * kTileK, c0 = ct * TC, r = p.r;
+    const long long ER = (long long)p.nr * p.nrhs;
+    for (int e = threadIdx.x; e < kTileK * TC; e += 256) {
+        const int kk = e / TC, cc = e - kk * TC, k = k0 + kk, cp = c0 + cc;
+        tile[kk][cc] = (k < p.nr && cp < p.nrhs) ? p.R[elem_index(b, (long long)k * p.nrhs + cp, ER, p.W)] : 0.0;
+    }
+    __syncthreads();
+    double *out = p.ws + li * (long long)p.nrp * p.ncp + (long long)p.nrp * p.nrp;
+    const int ncr = p.ncp - p.nrp;  // padded right-hand side columns
+    for (int e = threadIdx.x; e < kTileK * TC; e += 256) {
+        const int cc = e / kTileK, kk = e - cc * kTileK, c = c0 + cc, k = k0 + kk;
+        if (c >= ncr) continue;
+        double v = 0.0;
+        if (k < p.nr && c < p.nrhs) {
+            const int blk = cc / r, a2 = cc - blk * r;
+            for (int a = 0; a < r; ++a) v += tile[kk][blk * r + a] * p.Q[a2 * r + a];
+        }
+        out[(long long)c * p.nrp + k] = v;
+    }
 }
 
 // ---- factor / eliminate: one workgroup per instance ----
@@ -341,7 +366,18 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         const long long pblocks = (elems + 255) / 256;
         if (pblocks > 0x7fffffffLL || count > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
         PackArgs pa{H, R, Q, ws, first, count, W, nr, nrhs, r, nrp, ncp};
-        hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa);
+        if (Q != nullptr && r <= kTileCMax) {
+            const long long hblocks = (count * (long long)nrp * nrp + 255) / 256;
+            hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)hblocks), dim3(256), 0, s, pa, nrp);
+            const int TC = r * (kTileCMax / r), CT = (ncp - nrp + TC - 1) / TC, KT = nrp / kTileK;
+            const long long tiles = count * (long long)CT * KT;
+            if (tiles > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL(lu_pack_gamma_kernel, dim3((unsigned)tiles), dim3(256), 0, s, pa, TC, CT, KT);
+        } else if (Q != nullptr) {
+            return MPCX_ERR_UNSUPPORTED;  // weight blocks wider than 64 outputs are not served by the blocked solver
+        } else {
+            hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa, ncp);
+        }
         LuArgs la{ws, failed, count, nrp, ncp};
         hipLaunchKernelGGL(lu_block_kernel, dim3((unsigned)count), dim3(kThreads), lds_bytes, s, la);
         const long long uthreads = count * (long long)(nrp / kNB) * nrhs;
