@@ -61,7 +61,7 @@ int check_common(mpcx_ctx *ctx, const mpcx_dims *d, long long *W) {
 
 // Workspace of the blocked solver: room for the whole batch when that is at most kLuCap, else for as many instances
 // as kLuCap holds (the solver then runs the batch in several launches); never less than one instance.
-constexpr size_t kLuCap = (size_t)16 << 30;
+constexpr size_t kLuCap = (size_t)64 << 30;
 int ensure_lu_work(mpcx_ctx *ctx, int nr, int nrhs, long long batch, size_t *doubles) {
     *doubles = 0;
     if (solve_fits_on_chip(nr, nrhs) || !solve_large_supports(nr)) return MPCX_OK;
@@ -363,6 +363,50 @@ int mpcx_rollout_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const d
     return MPCX_OK;
 }
 
+namespace {
+// Host-pointer round trip shared by the host variants: inputs up, outputs and the optional info array down.
+struct HostIo {
+    const double *hin[8];
+    long long nin[8];
+    int ni;
+    double *hout[4];
+    long long nout[4];
+    int no;
+    int32_t *hinfo;
+    long long ninfo;
+    const double *din[8];
+    double *dout[4];
+    int32_t *dinfo;
+};
+int host_stage(mpcx_ctx *ctx, HostIo &io) {
+    size_t off_in[8], off_out[4], total = 0;
+    for (int i = 0; i < io.ni; ++i) { off_in[i] = total; if (io.hin[i]) total += align256((size_t)io.nin[i] * sizeof(double)); }
+    for (int i = 0; i < io.no; ++i) { off_out[i] = total; if (io.hout[i]) total += align256((size_t)io.nout[i] * sizeof(double)); }
+    const size_t off_info = total;
+    if (io.hinfo) total += align256((size_t)io.ninfo * sizeof(int32_t));
+    int rc = ensure_work(ctx, total ? total : 256);
+    if (rc != MPCX_OK) return rc;
+    char *base = (char *)ctx->work;
+    for (int i = 0; i < io.ni; ++i) {
+        io.din[i] = io.hin[i] ? (const double *)(base + off_in[i]) : nullptr;
+        if (io.hin[i] && io.nin[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync((void *)io.din[i], io.hin[i], (size_t)io.nin[i] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (int i = 0; i < io.no; ++i) io.dout[i] = io.hout[i] ? (double *)(base + off_out[i]) : nullptr;
+    io.dinfo = io.hinfo ? (int32_t *)(base + off_info) : nullptr;
+    return MPCX_OK;
+}
+int host_collect(mpcx_ctx *ctx, HostIo &io, int rc) {
+    if (rc != MPCX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    for (int i = 0; i < io.no; ++i)
+        if (io.hout[i] && io.nout[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(io.hout[i], io.dout[i], (size_t)io.nout[i] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (io.hinfo) HIP_TRY(ctx, hipMemcpyAsync(io.hinfo, io.dinfo, (size_t)io.ninfo * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MPCX_OK;
+}
+}  // namespace
+
 int mpcx_qp_solve_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *fvec, double *u_seq,
                           int32_t *info, void *stream) {
     long long W = 1;
@@ -400,27 +444,6 @@ int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, con
     return MPCX_OK;
 }
 
-namespace {
-// host-pointer wrapper shared by solve and gain: inputs in[i] (elements nin[i]) up, outputs down, info down
-int host_roundtrip(mpcx_ctx *ctx, int n_in, const double *const *hin, const long long *nin, double *hout, long long nout,
-                   int32_t *hinfo, long long batch, const double **din, double **dout, int32_t **dinfo) {
-    size_t off[4], total = 0;
-    for (int i = 0; i < n_in; ++i) { off[i] = total; total += align256((size_t)nin[i] * sizeof(double)); }
-    const size_t off_out = total; total += align256((size_t)nout * sizeof(double));
-    const size_t off_info = total; total += align256((size_t)batch * sizeof(int32_t));
-    int rc = ensure_work(ctx, total);
-    if (rc != MPCX_OK) return rc;
-    char *base = (char *)ctx->work;
-    for (int i = 0; i < n_in; ++i) {
-        din[i] = (const double *)(base + off[i]);
-        HIP_TRY(ctx, hipMemcpyAsync((void *)din[i], hin[i], (size_t)nin[i] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    }
-    *dout = (double *)(base + off_out);
-    *dinfo = hinfo ? (int32_t *)(base + off_info) : nullptr;
-    (void)hout;
-    return MPCX_OK;
-}
-}  // namespace
 
 int mpcx_qp_solve_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *fvec, double *u_seq, int32_t *info) {
     long long W = 1;
@@ -430,18 +453,17 @@ int mpcx_qp_solve_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const 
     if (!H || !fvec || !u_seq) return fail(ctx, MPCX_ERR_NULL, "H, fvec and u_seq are required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long vm = (long long)d->v * d->m;
-    const double *hin[2] = {H, fvec};
-    const long long nin[2] = {mpcx_array_elems(d->batch, d->interleave, vm * vm), mpcx_array_elems(d->batch, d->interleave, vm)};
-    const long long nout = nin[1];
-    const double *din[2]; double *dout; int32_t *dinfo;
-    rc = host_roundtrip(ctx, 2, hin, nin, u_seq, nout, info, d->batch, din, &dout, &dinfo);
+    HostIo io{};
+    io.ni = 2;
+    io.hin[0] = H; io.nin[0] = mpcx_array_elems(d->batch, d->interleave, vm * vm);
+    io.hin[1] = fvec; io.nin[1] = mpcx_array_elems(d->batch, d->interleave, vm);
+    io.no = 1;
+    io.hout[0] = u_seq; io.nout[0] = io.nin[1];
+    io.hinfo = info; io.ninfo = d->batch;
+    rc = host_stage(ctx, io);
     if (rc != MPCX_OK) return rc;
-    rc = mpcx_qp_solve_f64_dev(ctx, d, din[0], din[1], dout, dinfo, (void *)ctx->stream);
-    if (rc != MPCX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-    HIP_TRY(ctx, hipMemcpyAsync(u_seq, dout, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (info) HIP_TRY(ctx, hipMemcpyAsync(info, dinfo, (size_t)d->batch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return MPCX_OK;
+    rc = mpcx_qp_solve_f64_dev(ctx, d, io.din[0], io.din[1], io.dout[0], io.dinfo, (void *)ctx->stream);
+    return host_collect(ctx, io, rc);
 }
 
 int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *Gamma, const double *W4, double *gain,
@@ -453,19 +475,18 @@ int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const d
     if (!H || !Gamma || !W4 || !gain) return fail(ctx, MPCX_ERR_NULL, "H, Gamma, W4 and gain are required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long vm = (long long)d->v * d->m, fr = (long long)d->f * d->r;
-    const double *hin[3] = {H, Gamma, W4};
-    const long long nin[3] = {mpcx_array_elems(d->batch, d->interleave, vm * vm), mpcx_array_elems(d->batch, d->interleave, fr * vm),
-                              (long long)d->r * d->r};
-    const long long nout = mpcx_array_elems(d->batch, d->interleave, vm * fr);
-    const double *din[3]; double *dout; int32_t *dinfo;
-    rc = host_roundtrip(ctx, 3, hin, nin, gain, nout, info, d->batch, din, &dout, &dinfo);
+    HostIo io{};
+    io.ni = 3;
+    io.hin[0] = H; io.nin[0] = mpcx_array_elems(d->batch, d->interleave, vm * vm);
+    io.hin[1] = Gamma; io.nin[1] = mpcx_array_elems(d->batch, d->interleave, fr * vm);
+    io.hin[2] = W4; io.nin[2] = (long long)d->r * d->r;
+    io.no = 1;
+    io.hout[0] = gain; io.nout[0] = mpcx_array_elems(d->batch, d->interleave, vm * fr);
+    io.hinfo = info; io.ninfo = d->batch;
+    rc = host_stage(ctx, io);
     if (rc != MPCX_OK) return rc;
-    rc = mpcx_qp_gain_f64_dev(ctx, d, din[0], din[1], din[2], dout, dinfo, (void *)ctx->stream);
-    if (rc != MPCX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-    HIP_TRY(ctx, hipMemcpyAsync(gain, dout, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (info) HIP_TRY(ctx, hipMemcpyAsync(info, dinfo, (size_t)d->batch * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return MPCX_OK;
+    rc = mpcx_qp_gain_f64_dev(ctx, d, io.din[0], io.din[1], io.din[2], io.dout[0], io.dinfo, (void *)ctx->stream);
+    return host_collect(ctx, io, rc);
 }
 
 int mpcx_c2d_backward_euler_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *Ac, const double *Bc, double dt,
@@ -515,49 +536,6 @@ int mpcx_plants_f64_dev(mpcx_ctx *ctx, int kind, int64_t batch, int64_t interlea
     return MPCX_OK;
 }
 
-namespace {
-// Generic host-pointer round trip: ni inputs up, run, no outputs + optional info down.
-struct HostIo {
-    const double *hin[8];
-    long long nin[8];
-    int ni;
-    double *hout[4];
-    long long nout[4];
-    int no;
-    int32_t *hinfo;
-    long long ninfo;
-    const double *din[8];
-    double *dout[4];
-    int32_t *dinfo;
-};
-int host_stage(mpcx_ctx *ctx, HostIo &io) {
-    size_t off_in[8], off_out[4], total = 0;
-    for (int i = 0; i < io.ni; ++i) { off_in[i] = total; if (io.hin[i]) total += align256((size_t)io.nin[i] * sizeof(double)); }
-    for (int i = 0; i < io.no; ++i) { off_out[i] = total; if (io.hout[i]) total += align256((size_t)io.nout[i] * sizeof(double)); }
-    const size_t off_info = total;
-    if (io.hinfo) total += align256((size_t)io.ninfo * sizeof(int32_t));
-    int rc = ensure_work(ctx, total ? total : 256);
-    if (rc != MPCX_OK) return rc;
-    char *base = (char *)ctx->work;
-    for (int i = 0; i < io.ni; ++i) {
-        io.din[i] = io.hin[i] ? (const double *)(base + off_in[i]) : nullptr;
-        if (io.hin[i] && io.nin[i] > 0)
-            HIP_TRY(ctx, hipMemcpyAsync((void *)io.din[i], io.hin[i], (size_t)io.nin[i] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    }
-    for (int i = 0; i < io.no; ++i) io.dout[i] = io.hout[i] ? (double *)(base + off_out[i]) : nullptr;
-    io.dinfo = io.hinfo ? (int32_t *)(base + off_info) : nullptr;
-    return MPCX_OK;
-}
-int host_collect(mpcx_ctx *ctx, HostIo &io, int rc) {
-    if (rc != MPCX_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-    for (int i = 0; i < io.no; ++i)
-        if (io.hout[i] && io.nout[i] > 0)
-            HIP_TRY(ctx, hipMemcpyAsync(io.hout[i], io.dout[i], (size_t)io.nout[i] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (io.hinfo) HIP_TRY(ctx, hipMemcpyAsync(io.hinfo, io.dinfo, (size_t)io.ninfo * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return MPCX_OK;
-}
-}  // namespace
 
 int mpcx_c2d_backward_euler_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *Ac, const double *Bc, double dt, double *A,
                                 double *B, int32_t *info) {
