@@ -5,7 +5,7 @@
 // kernel) and every MFMA operand is one LDS read at a shifted index with a zero mask.  With W4 = blockdiag(Q) the
 // other operand, T = W4 Gamma, has the same structure over the vectors Q G_k.
 //
-// Tiling: a wavefront owns a 32 x 32 tile of H as 2 x 2 accumulators of v_mfma_f64_16x16x4_f64 and walks the
+// Tiling: a wavefront owns a 48 x 48 tile of H as 3 x 3 accumulators of v_mfma_f64_16x16x4_f64 and walks the
 // contraction index rho in steps of 4, starting at the first row where both operand tiles can be non-zero (Gamma
 // is block lower-triangular: column block k is zero above row k r).  The product is formed transposed
 // (D[i][j] = H[a0 + j][b0 + i]) so that the 16 lanes sharing an accumulator register hold 16 consecutive rows of
@@ -130,46 +130,47 @@ __global__ __launch_bounds__(kThreads) void hessian_mfma_kernel(QpArgs p) {
     }
     lds_barrier();
 
-    // ---- 32 x 32 tiles of H, one per wavefront at a time ----
+    // ---- kT x kT tiles of H (kT = 16 kU), one per wavefront at a time: kU + kU operand reads feed kU * kU MFMAs ----
+    constexpr int kU = 3, kT = 16 * kU;
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int nt = (VM + 31) >> 5;
+    const int nt = (VM + kT - 1) / kT;
     double *gH = p.H + b * (long long)VM * VM;
     for (int tile = wave; tile < nt * nt; tile += kThreads / 64) {
         const int tb = tile / nt, ta = tile - tb * nt;  // consecutive waves walk down a column of tiles
-        const int a0 = ta << 5, b0 = tb << 5;
+        const int a0 = ta * kT, b0 = tb * kT;
         // A operand rows = columns b0.. of T, B operand columns = columns a0.. of Gamma (transposed product)
-        ColRef tcol[2], gcol[2];
+        ColRef tcol[kU], gcol[kU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kU; ++u) {
             tcol[u] = col_ref(b0 + 16 * u + l15, VM, m, r, v, FR, nl, sQG, sQS);
             gcol[u] = col_ref(a0 + 16 * u + l15, VM, m, r, v, FR, nl, sG, sS);
         }
         // first row where both operand tiles can be non-zero: the larger of the two tiles' smallest shifts
         const int sa = (a0 / m) * r, sb = (b0 / m) * r;
         const int kstart = (sa > sb ? sa : sb) & ~3;
-        d4 acc[2][2];
+        d4 acc[kU][kU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < kU; ++u)
 #pragma unroll
-            for (int w = 0; w < 2; ++w) acc[u][w] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int w = 0; w < kU; ++w) acc[u][w] = (d4){0.0, 0.0, 0.0, 0.0};
         for (int rho0 = kstart; rho0 < FR; rho0 += 4) {
             const int rho = rho0 + kq;
-            double av[2], bv[2];
+            double av[kU], bv[kU];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < kU; ++u) {
                 av[u] = col_at(tcol[u], rho, FR);
                 bv[u] = col_at(gcol[u], rho, FR);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < kU; ++u)
 #pragma unroll
-                for (int w = 0; w < 2; ++w) acc[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[w], acc[u][w], 0, 0, 0);
+                for (int w = 0; w < kU; ++w) acc[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[w], acc[u][w], 0, 0, 0);
         }
         // D[i][j] = H[a0 + 16 w + j][b0 + 16 u + i]; lane holds j = l15 and i = kq + 4 reg
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < kU; ++u)
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
+            for (int w = 0; w < kU; ++w) {
                 const int row = a0 + 16 * w + l15;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
