@@ -130,7 +130,7 @@ int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, 
  *   mpcx_qp_solve:  u_seq (v m per instance) = -H^-1 fvec: the optimal input sequence; its first m entries are the
  *                   move the reference applies (controller.rs:130-134 with gain s = -H^-1 fvec).
  *   mpcx_qp_gain:   gain ((v m) x (f r) per instance) = H^-1 Gamma^T W4, the reference's gain_matrix
- *                   (controller.rs:93-96); W4 is the r x r block (MPCX_WEIGHTS_BLOCK only).
+ *                   (controller.rs:93-96); W4 is the r x r block or the dense (f r) x (f r) matrix, per dims->weights_mode.
  * `info` (int32 per instance, plain array of `batch` entries, may be NULL) is 0 on success and 1 where the reference
  * returns Err("Matrix inversion failed") (controller.rs:93-95): an exactly zero or non-finite pivot; the outputs of
  * such an instance are NaN.  The call itself still returns MPCX_OK.  H, fvec, Gamma, u_seq, gain use dims->interleave.

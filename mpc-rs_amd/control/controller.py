@@ -18,29 +18,6 @@ def _block_of(mat_w4: np.ndarray, f: int, r: int):
     return q if np.array_equal(rebuilt, mat_w4) else None
 
 
-def _try_inverse(h: np.ndarray):
-    """nalgebra's try_inverse semantics on the host: LU with partial pivoting, None on an exactly zero pivot."""
-    n = h.shape[0]
-    lu = np.array(h, dtype=np.float64, copy=True)
-    perm = np.arange(n)
-    for k in range(n):
-        piv = k + int(np.argmax(np.abs(lu[k:, k])))
-        if lu[piv, k] == 0.0 or not np.isfinite(lu[piv, k]):
-            return None
-        if piv != k:
-            lu[[k, piv]] = lu[[piv, k]]
-            perm[[k, piv]] = perm[[piv, k]]
-        lu[k + 1:, k] /= lu[k, k]
-        lu[k + 1:, k + 1:] -= np.outer(lu[k + 1:, k], lu[k, k + 1:])
-    inv = np.eye(n)[perm]
-    for k in range(n):  # forward substitution, unit lower
-        inv[k + 1:] -= np.outer(lu[k + 1:, k], inv[k])
-    for k in range(n - 1, -1, -1):  # back substitution
-        inv[k] /= lu[k, k]
-        inv[:k] -= np.outer(lu[:k, k], inv[k])
-    return inv
-
-
 class mpc:  # noqa: N801  (module name in the reference)
     class Controller:
         def __init__(self, model, f, mat_o, gain_matrix, desired_ctrl_traj_total):
@@ -69,18 +46,24 @@ class mpc:  # noqa: N801  (module name in the reference)
         @staticmethod
         def form_lifted_matrices(mat_a, mat_b, mat_c, f: int, v: int, mat_w3, mat_w4):
             """controller.rs:16-99: returns (mat_o, mat_m, gain_matrix); raises RuntimeError("Matrix inversion failed")
-            where the reference returns that Err (:93-95)."""
+            where the reference returns that Err (:93-95).  The inversion and H^-1 M^T W4 run on the device
+            (mpcx_qp_gain: LU with partial pivoting, status per instance)."""
             mat_o, mat_m, h = mpc.Controller.lifted_and_hessian(mat_a, mat_b, mat_c, f, v, mat_w3, mat_w4)
-            tmp2 = _try_inverse(h)
-            if tmp2 is None:
+            mat_w4 = np.asarray(mat_w4, dtype=np.float64)
+            m, r = np.asarray(mat_b).shape[1], np.asarray(mat_c).shape[0]
+            q = _block_of(mat_w4, f, r)
+            mode, w4 = (ffi.WEIGHTS_BLOCK, q) if q is not None else (ffi.WEIGHTS_DENSE, mat_w4)
+            gain, info = context().qp_gain(h[None], mat_m[None], w4, m, r, f, v, weights_mode=mode)
+            if info[0] != 0:
                 raise RuntimeError("Matrix inversion failed")
-            gain_matrix = tmp2 @ mat_m.T @ np.asarray(mat_w4, dtype=np.float64)  # :96
-            return mat_o, mat_m, gain_matrix
+            return mat_o, mat_m, gain[0]
 
         @classmethod
         def new(cls, model: DiscreteStateSpaceModel, f: int, v: int, q0: float, q_other: float, pred_weight: float,
-                desired_ctrl_traj: np.ndarray) -> "mpc.Controller":
-            """controller.rs:137-207."""
+                desired_ctrl_traj: np.ndarray, all_elements: bool = True) -> "mpc.Controller":
+            """controller.rs:137-207.  `all_elements` (an addition, default = the reference) keeps the reference's weight
+            blocks, every element of an m x m / r x r block set to the weight (:164-165, :184); False builds q I blocks,
+            which is what a plant with several inputs or outputs needs for the Hessian to be invertible."""
             m = model.get_mat_b().shape[1]
             r = model.get_mat_c().shape[0]
             w1 = np.zeros((v * m, v * m))  # :149-161
@@ -89,11 +72,12 @@ class mpc:  # noqa: N801  (module name in the reference)
                 w1[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.eye(m)
                 if i >= 1:
                     w1[i * m:(i + 1) * m, (i - 1) * m:i * m] = -np.eye(m)
-                w2[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.full((m, m), q0 if i == 0 else q_other)
+                qi = q0 if i == 0 else q_other
+                w2[i * m:(i + 1) * m, i * m:(i + 1) * m] = np.full((m, m), qi) if all_elements else qi * np.eye(m)
             w3 = w1.T @ (w2 @ w1)  # :177
             w4 = np.zeros((f * r, f * r))  # :179-185
             for i in range(f):
-                w4[i * r:(i + 1) * r, i * r:(i + 1) * r] = np.full((r, r), pred_weight)
+                w4[i * r:(i + 1) * r, i * r:(i + 1) * r] = np.full((r, r), pred_weight) if all_elements else pred_weight * np.eye(r)
             mat_o, _, gain = cls.form_lifted_matrices(model.get_mat_a(), model.get_mat_b(), model.get_mat_c(), f, v, w3, w4)
             return cls(model, f, mat_o, gain, np.array(desired_ctrl_traj, dtype=np.float64, copy=True))
 
@@ -113,3 +97,30 @@ class mpc:  # noqa: N801  (module name in the reference)
             vec_s = seg - (self._mat_o @ np.asarray(state, dtype=np.float64).reshape(-1, 1))  # :125-127
             seq = self._gain_matrix @ vec_s  # :130
             return np.array([seq[0, 0]])  # :131-134
+
+        # ---- additions to the reference API (it stops at one input and one output, :119-122 and :131-132) ----
+        def compute_control_input_mimo(self, timestep: int, state: np.ndarray) -> np.ndarray:
+            """The move for m inputs and r outputs: the first m entries of gain (window - O x), the window being rows
+            timestep .. timestep + f of a (time_steps x r) trajectory stacked time-major."""
+            m = self._model.get_mat_b().shape[1]
+            traj = np.asarray(self.desired_ctrl_traj_total, dtype=np.float64)
+            if timestep + self._f > traj.shape[0]:
+                raise IndexError("Matrix slicing out of bounds.")
+            window = traj[timestep:timestep + self._f, :].reshape(-1, 1)
+            vec_s = window - (self._mat_o @ np.asarray(state, dtype=np.float64).reshape(-1, 1))
+            return (self._gain_matrix @ vec_s)[:m, 0]
+
+        def closed_loop(self, steps: int, x0: np.ndarray):
+            """The loop of src/main.rs:51-71 in one device call: returns (states n x (steps+1), inputs m x steps,
+            outputs r x (steps+1)) with outputs[:, 0] = C x0 as main.rs:40-41 records it."""
+            a, b, c = self._model.get_mat_a(), self._model.get_mat_b(), self._model.get_mat_c()
+            r, v = c.shape[0], self._gain_matrix.shape[0] // b.shape[1]
+            traj = np.asarray(self.desired_ctrl_traj_total, dtype=np.float64)
+            if steps + self._f > traj.shape[0]:
+                raise IndexError("Matrix slicing out of bounds.")
+            ref = np.ascontiguousarray(traj[:steps + self._f, :].T).reshape(r, steps + self._f)
+            x0 = np.asarray(x0, dtype=np.float64).reshape(1, -1)
+            out = context().closed_loop(a[None], b[None], c[None], x0, self._mat_o[None], self._gain_matrix[None], ref, steps,
+                                        self._f, v)
+            outputs = np.concatenate([(c @ x0[0]).reshape(r, 1), out["Y"][0]], axis=1)
+            return out["X"][0], out["U"][0], outputs

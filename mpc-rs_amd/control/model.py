@@ -1,5 +1,5 @@
-"""Mirror of src/control/model.rs: the DiscreteStateSpaceModel trait and the two plants, discretised with the
-reference's backward-Euler rule A = (I - Ac dt)^-1, B = A (Bc dt) (model.rs:55-58, 138-141)."""
+"""Mirror of src/control/model.rs: the DiscreteStateSpaceModel trait and the two plants.  Model::new runs on the device
+(continuous matrices from the parameters, backward Euler A = (I - Ac dt)^-1, B = A (Bc dt), model.rs:55-58, 138-141)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -22,14 +22,14 @@ class DiscreteStateSpaceModel:
     def get_sampling_dt(self) -> float:
         return self._dt
 
-    def _discretise(self, ac: np.ndarray, bc: np.ndarray, cc: np.ndarray, dt: float) -> None:
-        t = np.eye(ac.shape[0]) - ac * dt
-        if np.linalg.det(t) == 0.0:  # try_inverse().unwrap() panics (model.rs:56, 139)
+    def _from_parameters(self, kind: int, params, dt: float) -> None:
+        """Model::new on the device (mpcx_plants: continuous matrices from the parameters, then backward Euler)."""
+        from .. import ffi
+        from .simulator import context
+        a, b, c, info = context().plants(kind, np.asarray([params], dtype=np.float64), float(dt))
+        if info[0] != 0:  # try_inverse().unwrap() panics (model.rs:56, 139)
             raise ZeroDivisionError("called `Option::unwrap()` on a `None` value: I - Ac dt is singular")
-        self._a = np.linalg.inv(t)
-        self._b = self._a @ (bc * dt)
-        self._c = cc
-        self._dt = float(dt)
+        self._a, self._b, self._c, self._dt = a[0], b[0], c[0], float(dt)
 
 
 class dc_motor:  # noqa: N801  (module name in the reference)
@@ -44,11 +44,9 @@ class dc_motor:  # noqa: N801  (module name in the reference)
 
     class Model(DiscreteStateSpaceModel):
         def __init__(self, params: "dc_motor.Parameters", sampling_dt: float):
-            p = params
-            ac = np.array([[-p.b / p.j, p.k / p.j], [-p.k / p.l, -p.r / p.l]])  # model.rs:47-50
-            bc = np.array([[0.0], [1.0 / p.l]])
-            cc = np.array([[1.0, 0.0]])
-            self._discretise(ac, bc, cc, sampling_dt)
+            from .. import ffi
+            p = params  # model.rs:47-58; parameter order of the device entry point: b, j, k, l, r
+            self._from_parameters(ffi.PLANT_DC_MOTOR, [p.b, p.j, p.k, p.l, p.r], sampling_dt)
 
 
 class mpc:  # noqa: N801
@@ -64,13 +62,6 @@ class mpc:  # noqa: N801
 
     class Model(DiscreteStateSpaceModel):
         def __init__(self, params: "mpc.Parameters", sampling_dt: float):
-            p = params
-            ac = np.array([  # model.rs:128-133
-                [0.0, 1.0, 0.0, 0.0],
-                [-(p.k1 + p.k2) / p.m1, -(p.d1 + p.d2) / p.m1, p.k2 / p.m1, p.d2 / p.m1],
-                [0.0, 0.0, 0.0, 1.0],
-                [p.k2 / p.m2, p.d2 / p.m2, -p.k2 / p.m2, -p.d2 / p.m2],
-            ])
-            bc = np.array([[0.0], [0.0], [0.0], [1.0 / p.m2]])
-            cc = np.array([[1.0, 0.0, 0.0, 0.0]])
-            self._discretise(ac, bc, cc, sampling_dt)
+            from .. import ffi
+            p = params  # model.rs:128-141; parameter order of the device entry point: m1, m2, k1, k2, d1, d2
+            self._from_parameters(ffi.PLANT_TWO_MASS, [p.m1, p.m2, p.k1, p.k2, p.d1, p.d2], sampling_dt)

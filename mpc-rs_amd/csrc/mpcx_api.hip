@@ -431,14 +431,19 @@ int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, con
     int rc = check_common(ctx, d, &W);
     if (rc != MPCX_OK) return rc;
     if (d->f < 1 || d->v < 1 || d->v > d->f) return fail(ctx, MPCX_ERR_DIMS, "need f >= 1 and 1 <= v <= f");
-    if (d->weights_mode != MPCX_WEIGHTS_BLOCK) return fail(ctx, MPCX_ERR_UNSUPPORTED, "gain: W4 must be the r x r block");
+    if (d->weights_mode != MPCX_WEIGHTS_BLOCK && d->weights_mode != MPCX_WEIGHTS_DENSE)
+        return fail(ctx, MPCX_ERR_DIMS, "unknown weights_mode %d", d->weights_mode);
     if (d->batch == 0) return MPCX_OK;
     if (!H || !Gamma || !W4 || !gain) return fail(ctx, MPCX_ERR_NULL, "H, Gamma, W4 and gain are required");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     size_t wsd = 0;
     rc = ensure_lu_work(ctx, d->v * d->m, d->f * d->r, d->batch, &wsd);
     if (rc != MPCX_OK) return rc;
-    rc = launch_qp_gain(H, Gamma, W4, gain, info, d->batch, W, d->m, d->r, d->f, d->v, (double *)ctx->lu_work, wsd, (hipStream_t)stream);
+    rc = (d->weights_mode == MPCX_WEIGHTS_DENSE)
+             ? launch_qp_gain_dense(H, Gamma, W4, gain, info, d->batch, W, d->m, d->r, d->f, d->v, (double *)ctx->lu_work, wsd,
+                                    (hipStream_t)stream)
+             : launch_qp_gain(H, Gamma, W4, gain, info, d->batch, W, d->m, d->r, d->f, d->v, (double *)ctx->lu_work, wsd,
+                              (hipStream_t)stream);
     if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "gain: v m = %d is beyond what the solver holds on chip", d->v * d->m);
     if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "gain launch");
     return MPCX_OK;
@@ -479,7 +484,7 @@ int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const d
     io.ni = 3;
     io.hin[0] = H; io.nin[0] = mpcx_array_elems(d->batch, d->interleave, vm * vm);
     io.hin[1] = Gamma; io.nin[1] = mpcx_array_elems(d->batch, d->interleave, fr * vm);
-    io.hin[2] = W4; io.nin[2] = (long long)d->r * d->r;
+    io.hin[2] = W4; io.nin[2] = (d->weights_mode == MPCX_WEIGHTS_DENSE) ? fr * fr : (long long)d->r * d->r;
     io.no = 1;
     io.hout[0] = gain; io.nout[0] = mpcx_array_elems(d->batch, d->interleave, vm * fr);
     io.hinfo = info; io.ninfo = d->batch;

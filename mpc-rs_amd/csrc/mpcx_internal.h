@@ -56,6 +56,8 @@ int launch_c2d_general(const double *Ac, const double *Bc, double dt, double *A,
 int launch_plants(int kind, const double *params, double dt, double *A, double *B, double *C, int *info, long long batch,
                   long long W, hipStream_t s);
 bool solve_fits_on_chip(int nr, int nrhs);
+int launch_qp_gain_dense(const double *H, const double *Gamma, const double *W4, double *gain, int *info, long long batch,
+                         long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s);
 size_t solve_large_ws_doubles(int nr, int nrhs);
 bool solve_large_supports(int nr);
 int launch_solve_large(const double *H, const double *R, const double *Q, int r, double *X, int *info, long long batch,

@@ -332,6 +332,36 @@ int launch_solve_inplace(const double *H, double *X, int *info, long long batch,
     return launch_solve_large(H, X, nullptr, 0, X, info, batch, W, nr, nrhs, 0, ws, ws_doubles, s);
 }
 
+namespace {
+// R[k][c] = sum_row Gamma[row][k] W4[row][c] for a dense (f r) x (f r) weight: the literal M^T W4 of controller.rs:96.
+__global__ __launch_bounds__(256) void gamma_t_w4_dense_kernel(const double *Gamma, const double *W4, double *out, long long batch,
+                                                               long long W, int nr, int fr) {
+    const long long per = (long long)nr * fr;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= batch * per) return;
+    const long long b = idx / per, e = idx - b * per;
+    const int c = (int)(e / nr), k = (int)(e - (long long)c * nr);
+    double s = 0.0;
+    for (int row = 0; row < fr; ++row) s += Gamma[elem_index(b, (long long)k * fr + row, per, W)] * W4[(long long)c * fr + row];
+    out[elem_index(b, e, per, W)] = s;
+}
+
+}  // namespace
+
+// Dense W4 ((f r) x (f r), the literal argument of form_lifted_matrices): compatibility path, right-hand side formed by
+// a plain kernel, then solved in place.
+int launch_qp_gain_dense(const double *H, const double *Gamma, const double *W4, double *gain, int *info, long long batch,
+                         long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s) {
+    const int nr = v * m, nrhs = f * r;
+    const long long total = batch * (long long)nr * nrhs;
+    if ((total + 255) / 256 > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gamma_t_w4_dense_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Gamma, W4, gain, batch, W,
+                       nr, nrhs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return launch_solve_inplace(H, gain, info, batch, W, nr, nrhs, ws, ws_doubles, s);
+}
+
 int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double *gain, int *info, long long batch,
                    long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s) {
     const int nr = v * m, nrhs = f * r;

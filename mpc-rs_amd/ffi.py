@@ -227,11 +227,12 @@ class Context:
         self._check(self._lib.mpcx_qp_solve_f64(self._h, C.byref(d), _hp(hb), _hp(fb), _hp(out), info.ctypes.data_as(C.c_void_p)))
         return L.unpack(out, batch, vm, 1, interleave)[:, :, 0], info[:batch]
 
-    def qp_gain(self, H, Gamma, Q, m, r, f, v, interleave=L.INTERLEAVE_AOS):
-        """gain (batch, vm, fr) = H^-1 Gamma^T blockdiag(Q), and info (batch,)."""
+    def qp_gain(self, H, Gamma, Q, m, r, f, v, interleave=L.INTERLEAVE_AOS, weights_mode=WEIGHTS_BLOCK):
+        """gain (batch, vm, fr) = H^-1 Gamma^T W4 and info (batch,); Q is the r x r block of W4 (WEIGHTS_BLOCK) or the
+        dense (f r) x (f r) W4 itself (WEIGHTS_DENSE)."""
         H = np.asarray(H, dtype=np.float64)
         batch = H.shape[0]
-        d = make_dims(1, m, r, f, v, batch, 0, interleave)
+        d = make_dims(1, m, r, f, v, batch, 0, interleave, weights_mode)
         hb, gb, qb = L.pack(H, interleave), L.pack(np.asarray(Gamma, dtype=np.float64), interleave), L.colmajor(Q)
         out = np.full(max(L.array_elems(batch, interleave, v * m * f * r), 1), np.nan)
         info = np.full(max(batch, 1), -1, dtype=np.int32)
