@@ -88,27 +88,32 @@ class mpc:  # noqa: N801  (module name in the reference)
             out = context().rollout(a[None], b[None], c[None], np.asarray(state, dtype=np.float64).reshape(1, -1), u)
             return out["X"][0, :, 1].copy(), out["Y"][0, :, 0].copy()
 
-        def compute_control_input(self, timestep: int, state: np.ndarray) -> np.ndarray:
-            """controller.rs:117-135: first element of gain (traj[t..t+f] - O x), as a 1-vector (one input, one output)."""
-            traj = self.desired_ctrl_traj_total
+        def _first_move(self, timestep: int, state: np.ndarray) -> np.ndarray:
+            """gain (window - O x)[0 .. m) on the device: one step of the receding-horizon loop started at `state`
+            (mpcx_closed_loop with T = 1 keeps the reference's order: s first, then gain s)."""
+            a, b, c = self._model.get_mat_a(), self._model.get_mat_b(), self._model.get_mat_c()
+            r, v = c.shape[0], self._gain_matrix.shape[0] // b.shape[1]
+            traj = np.asarray(self.desired_ctrl_traj_total, dtype=np.float64)
             if timestep + self._f > traj.shape[0]:
                 raise IndexError("Matrix slicing out of bounds.")  # view_range panics at :121
-            seg = traj[timestep:timestep + self._f, :]
-            vec_s = seg - (self._mat_o @ np.asarray(state, dtype=np.float64).reshape(-1, 1))  # :125-127
-            seq = self._gain_matrix @ vec_s  # :130
-            return np.array([seq[0, 0]])  # :131-134
+            if traj.shape[1] != r:
+                raise ValueError("Matrix addition/subtraction dimensions mismatch.")  # :125
+            ref = np.zeros((r, self._f + 1))  # r x (T + f) with T = 1; the last column is never read
+            ref[:, :self._f] = traj[timestep:timestep + self._f, :].T
+            x = np.asarray(state, dtype=np.float64).reshape(1, -1)
+            out = context().closed_loop(a[None], b[None], c[None], x, self._mat_o[None], self._gain_matrix[None], ref, 1,
+                                        self._f, v)
+            return out["U"][0, :, 0].copy()
+
+        def compute_control_input(self, timestep: int, state: np.ndarray) -> np.ndarray:
+            """controller.rs:117-135: first element of gain (traj[t..t+f] - O x), as a 1-vector (one input, one output)."""
+            return self._first_move(timestep, state)[:1]  # :131-134
 
         # ---- additions to the reference API (it stops at one input and one output, :119-122 and :131-132) ----
         def compute_control_input_mimo(self, timestep: int, state: np.ndarray) -> np.ndarray:
             """The move for m inputs and r outputs: the first m entries of gain (window - O x), the window being rows
             timestep .. timestep + f of a (time_steps x r) trajectory stacked time-major."""
-            m = self._model.get_mat_b().shape[1]
-            traj = np.asarray(self.desired_ctrl_traj_total, dtype=np.float64)
-            if timestep + self._f > traj.shape[0]:
-                raise IndexError("Matrix slicing out of bounds.")
-            window = traj[timestep:timestep + self._f, :].reshape(-1, 1)
-            vec_s = window - (self._mat_o @ np.asarray(state, dtype=np.float64).reshape(-1, 1))
-            return (self._gain_matrix @ vec_s)[:m, 0]
+            return self._first_move(timestep, state)
 
         def closed_loop(self, steps: int, x0: np.ndarray):
             """The loop of src/main.rs:51-71 in one device call: returns (states n x (steps+1), inputs m x steps,

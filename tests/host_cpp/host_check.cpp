@@ -1,0 +1,175 @@
+// Exercises the C++ host API (mpc-rs_amd/host/control_sys_rs.hpp) the way a user of the reference crate would use the
+// Rust one, and prints every result as `name rows cols v...` (column-major) for tests/test_host_cpp.py, which compares
+// them with the CPU oracle.  Exit code 3: no usable GPU (the library has no host fallback).
+#include <cstdio>
+#include <memory>
+#include <string>
+
+#include "control_sys_rs.hpp"
+
+using namespace control_sys_rs;
+using namespace control_sys_rs::control;
+
+static void put(const char *name, const na::DMatrix &a) {
+    std::printf("%s %zu %zu", name, a.nrows(), a.ncols());
+    for (double x : a.as_slice()) std::printf(" %.17g", x);
+    std::printf("\n");
+}
+static void put(const char *name, const std::vector<double> &a, std::size_t rows, std::size_t cols) {
+    std::printf("%s %zu %zu", name, rows, cols);
+    for (double x : a) std::printf(" %.17g", x);
+    std::printf("\n");
+}
+static void put(const char *name, const na::DVector &a) { put(name, a.as_slice(), a.nrows(), 1); }
+
+int main() {
+    try {
+        // --- Model::new for both plants (model.rs:45-66, :126-149)
+        auto motor = std::make_shared<const model::dc_motor::Model>(model::dc_motor::Parameters(), 0.05);
+        auto two_mass = std::make_shared<const model::mpc::Model>(model::mpc::Parameters(), 0.05);
+        put("motor_A", motor->get_mat_a()); put("motor_B", motor->get_mat_b()); put("motor_C", motor->get_mat_c());
+        put("two_mass_A", two_mass->get_mat_a()); put("two_mass_B", two_mass->get_mat_b()); put("two_mass_C", two_mass->get_mat_c());
+        std::printf("motor_dt 1 1 %.17g\n", motor->get_sampling_dt());
+
+        // --- simulator::step and compute_system_response (simulator.rs:37-63)
+        {
+            auto [response, input, states] = simulator::step(*motor, 10.0);
+            put("step_response", response); put("step_input", input); put("step_states", states);
+            na::DMatrix u(1, 50);
+            for (std::size_t i = 0; i < 50; ++i) u(0, i) = std::sin(0.3 * (double)i);
+            na::DVector x0(4);
+            for (std::size_t i = 0; i < 4; ++i) x0[i] = 0.1 * (double)(i + 1);
+            const std::vector<double> resp = simulator::compute_system_response(*two_mass, u, x0);
+            put("response_two_mass", resp, 1, resp.size());
+            auto [r0, i0, s0] = simulator::step(*motor, 0.01);  // floor(0.01 / 0.05) = 0 samples
+            std::printf("step_empty 1 3 %zu %zu %zu\n", r0.ncols(), i0.ncols(), s0.ncols());
+        }
+
+        // --- trajectory (trajectory.rs:3-11), including its panic for lengths not divisible as it assumes
+        const na::DMatrix traj = trajectory::generate_pulse_trajectory(300);
+        put("trajectory", traj);
+        try {
+            trajectory::generate_pulse_trajectory(301);
+            std::printf("trajectory_301 1 1 0\n");
+        } catch (const Panic &) {
+            std::printf("trajectory_301 1 1 1\n");
+        }
+
+        // --- the scenario of main.rs: Controller::new, then 280 x (compute_control_input, propagate_dynamics)
+        {
+            auto mpc = controller::mpc::Controller::new_(motor, 20, 20, 0.0000000011, 0.0001, 10.0, traj);
+            put("motor_mat_o", mpc.mat_o()); put("motor_gain", mpc.gain_matrix());
+            const std::size_t steps = 280;
+            na::DVector x = na::DVector::zeros(2);
+            std::vector<double> inputs, outputs, states{0.0, 0.0};
+            for (std::size_t t = 0; t < steps; ++t) {
+                const na::DVector u = mpc.compute_control_input(t, x);
+                auto [xn, y] = mpc.propagate_dynamics(u, x);
+                inputs.push_back(u[0]); outputs.push_back(y[0]);
+                states.push_back(xn[0]); states.push_back(xn[1]);
+                x = xn;
+            }
+            put("loop_inputs", inputs, 1, steps); put("loop_outputs", outputs, 1, steps); put("loop_states", states, 2, steps + 1);
+            auto [S, U, Y] = mpc.closed_loop(steps, na::DVector::zeros(2));
+            put("loop1_states", S); put("loop1_inputs", U); put("loop1_outputs", Y);
+            try {
+                mpc.compute_control_input(281, x);  // 281 + 20 > 300: view_range panics (controller.rs:121)
+                std::printf("slice_panic 1 1 0\n");
+            } catch (const Panic &) {
+                std::printf("slice_panic 1 1 1\n");
+            }
+        }
+
+        // --- form_lifted_matrices with f > v and caller-made weights (controller.rs:16-99)
+        {
+            const std::size_t f = 6, v = 3;
+            na::DMatrix w3 = na::DMatrix::zeros(v, v), w4 = na::DMatrix::zeros(f, f);
+            for (std::size_t i = 0; i < v; ++i)
+                for (std::size_t j = 0; j < v; ++j) w3(i, j) = (i == j ? 0.5 + 0.1 * (double)i : 0.01 * (double)(i + 2 * j));
+            for (std::size_t i = 0; i < f; ++i) w4(i, i) = 3.0;
+            auto [O, M, G] = controller::mpc::Controller::form_lifted_matrices(two_mass->get_mat_a(), two_mass->get_mat_b(),
+                                                                                  two_mass->get_mat_c(), f, v, w3, w4);
+            put("flm_O", O); put("flm_M", M); put("flm_gain", G);
+            auto [O2, M2, H] = controller::mpc::Controller::form_lifted_matrices_and_hessian(
+                two_mass->get_mat_a(), two_mass->get_mat_b(), two_mass->get_mat_c(), f, v, w3, w4);
+            (void)O2; (void)M2;
+            put("flm_H", H);
+            // a W4 that is not a repeated block: the dense-weight path
+            for (std::size_t i = 0; i < f; ++i)
+                for (std::size_t j = 0; j < f; ++j) w4(i, j) = (i == j ? 2.0 + (double)i : 0.05 * (double)(i + j));
+            auto [O3, M3, G3] = controller::mpc::Controller::form_lifted_matrices(two_mass->get_mat_a(), two_mass->get_mat_b(),
+                                                                                     two_mass->get_mat_c(), f, v, w3, w4);
+            (void)O3; (void)M3;
+            put("flm_dense_w4", w4); put("flm_dense_gain", G3);
+            try {  // W4 of the wrong size: nalgebra panics in the product at controller.rs:92
+                controller::mpc::Controller::form_lifted_matrices(two_mass->get_mat_a(), two_mass->get_mat_b(), two_mass->get_mat_c(),
+                                                                  f, v, w3, na::DMatrix::zeros(f + 1, f + 1));
+                std::printf("shape_panic 1 1 0\n");
+            } catch (const Panic &) {
+                std::printf("shape_panic 1 1 1\n");
+            }
+        }
+
+        // --- the reference's own failure: two inputs and outputs with all-elements weight blocks make H singular,
+        //     Controller::new returns Err("Matrix inversion failed") (controller.rs:93-95, :164-165, :184)
+        {
+            na::DMatrix a = na::DMatrix::from_row_slice(2, 2, {0.9, 0.1, 0.0, 0.8});
+            na::DMatrix b = na::DMatrix::identity(2, 2), c = na::DMatrix::identity(2, 2);
+            auto mimo = std::make_shared<const model::Matrices>(a, b, c, 0.1);
+            na::DMatrix tr = na::DMatrix::from_element(30, 2, 1.0);
+            std::string msg = "none";
+            try {
+                controller::mpc::Controller::new_(mimo, 4, 4, 1e-3, 1e-3, 1.0, tr);
+            } catch (const Error &e) {
+                msg = e.what();
+            }
+            std::printf("mimo_err %s\n", msg.c_str());
+            // with q I blocks the same plant is controllable: the MIMO move on the device
+            auto ok = controller::mpc::Controller::new_(mimo, 4, 4, 1e-3, 1e-3, 1.0, tr, /*all_elements=*/false);
+            na::DVector st(2);
+            st[0] = 0.3; st[1] = -0.2;
+            put("mimo_gain", ok.gain_matrix()); put("mimo_mat_o", ok.mat_o());
+            put("mimo_move", ok.compute_control_input_mimo(0, st));
+        }
+
+        // --- additive batched API: 8 perturbed two-mass plants, instance-major
+        {
+            const std::size_t B = 8, n = 4, m = 1, r = 1, f = 20, v = 20, T = 40;
+            std::vector<double> a, b, c, x0, ref, u(T, 1.0);
+            for (std::size_t i = 0; i < B; ++i) {
+                const double s = 1.0 + 0.01 * (double)i;
+                const model::mpc::Model pm(model::mpc::Parameters::with(2.0 * s, 2.0 / s, 100.0 * s, 200.0, 1.0 * s, 5.0), 0.05);
+                a.insert(a.end(), pm.get_mat_a().as_slice().begin(), pm.get_mat_a().as_slice().end());
+                b.insert(b.end(), pm.get_mat_b().as_slice().begin(), pm.get_mat_b().as_slice().end());
+                c.insert(c.end(), pm.get_mat_c().as_slice().begin(), pm.get_mat_c().as_slice().end());
+                for (std::size_t k = 0; k < n; ++k) x0.push_back(0.05 * (double)(i + k));
+                for (std::size_t k = 0; k < f; ++k) ref.push_back(k < 10 ? 1.0 : 0.0);
+            }
+            na::DMatrix w3 = na::DMatrix::zeros(v, v);
+            for (std::size_t i = 0; i < v; ++i) {
+                w3(i, i) = (i == 0) ? 1.1e-9 + 1e-4 : (i == v - 1 ? 1e-4 : 2e-4);
+                if (i + 1 < v) { w3(i, i + 1) = -1e-4; w3(i + 1, i) = -1e-4; }
+            }
+            const na::DMatrix q = na::DMatrix::from_element(1, 1, 10.0);
+            const batch::QpBatch qp = batch::build_qp_batched(B, n, m, r, f, v, a, b, c, w3, q, x0, ref);
+            put("batch_A", a, n * n, B);
+            put("batch_phi", qp.phi, f * r * n, B); put("batch_gamma", qp.gamma, f * r * v * m, B);
+            put("batch_h", qp.h, v * m * v * m, B); put("batch_fvec", qp.fvec, v * m, B);
+            auto [gain, info] = batch::gain_batched(qp, q);
+            put("batch_gain", gain, v * m * f * r, B);
+            int bad = 0;
+            for (auto s : info) bad += (s != 0);
+            std::printf("batch_info 1 1 %d\n", bad);
+            auto [X, Y] = batch::simulate_batched(B, n, m, r, T, a, b, c, x0, u, /*shared_input=*/true);
+            put("batch_X", X, n * (T + 1), B); put("batch_Y", Y, r * T, B);
+        }
+        return 0;
+    } catch (const DeviceError &e) {
+        std::printf("device_error %d\n", e.code);
+        std::fprintf(stderr, "%s\n", e.what());
+        return 3;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "unexpected: %s\n", e.what());
+        return 1;
+    }
+}
