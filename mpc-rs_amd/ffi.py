@@ -14,7 +14,8 @@ import numpy as np
 from . import layout as L
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmpcx.so")
+# MPCX_LIB: developer override used to A/B differently built copies of the library; the default is the in-tree build
+LIB_PATH = os.environ.get("MPCX_LIB") or os.path.join(_HERE, "csrc", "libmpcx.so")
 
 OK = 0
 ERR_NULL, ERR_DIMS, ERR_LAYOUT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SINGULAR = -1, -2, -3, -4, -5, -6

@@ -1,0 +1,29 @@
+"""Phase stamps of the workgroup QP kernel (needs a library built with -DWG_EXP=8; diagnostic, GPU only)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mpc_rs_amd import ffi, layout as L, synth
+name = sys.argv[1]; count = int(sys.argv[2]); want = sys.argv[3].split("+")
+dev = torch.device("cuda", 0); ctx = ffi.Context(0)
+wl = synth.WORKLOADS[name]; n, m, r, f, v = wl["n"], wl["m"], wl["r"], wl["f"], wl["v"]
+d = synth.make_batch(name, count); il = 1
+to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+bufs = {k: to(L.pack(d[k], il)) for k in ("A", "B", "C")}
+bufs["x0"] = to(L.pack(d["x0"].reshape(count, n, 1), il)); bufs["ref"] = to(L.pack(d["ref"].reshape(count, f * r, 1), il))
+bufs["W3"] = to(L.colmajor(d["W3"])); bufs["Q"] = to(L.colmajor(d["Q"]))
+sizes = {"Phi": f * r * n, "Gamma": f * r * v * m, "H": v * m * v * m, "fvec": v * m}
+outs = {k: torch.zeros(count * e, dtype=torch.float64, device=dev) for k, e in sizes.items()}
+dims = ffi.make_dims(n, m, r, f, v, count, 0, il)
+ptr = lambda k: outs[k].data_ptr() if (k in want or k == "fvec") else None
+for _ in range(3):
+    ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["W3"].data_ptr(),
+                     bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(), ptr("Phi"), ptr("Gamma"), ptr("H"), ptr("fvec"), 0)
+torch.cuda.synchronize()
+st = outs["fvec"].cpu().numpy().reshape(count, v * m)[:, :10]
+names = ["load+recur", "S,QG,Z", "gamma(first)", "fvec", "sweep prep", "ga load", "sweep 1st half", "sweep 2nd half", "gamma(last)"]
+dt = np.diff(st, axis=1) / 100.0  # 100 MHz -> us
+mid = slice(count // 4, 3 * count // 4)
+for half in (0, 1):
+    sel = dt[mid][half::2]
+    print(("even" if half == 0 else "odd ") + " blocks: " + "  ".join(f"{nm} {x:6.1f}" for nm, x in zip(names, sel.mean(axis=0))) + f"  total {(st[mid][half::2, 9] - st[mid][half::2, 0]).mean() / 100:.1f} us")
+print("kernel span %.3f ms" % ((st[:, 9].max() - st[:, 0].min()) / 1e5))
