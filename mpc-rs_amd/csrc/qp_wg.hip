@@ -17,7 +17,9 @@
 // waits for all of them before a later load returns.  The four compute waves therefore never load from global
 // memory once their first store is out: everything they need is in LDS, and the shared weight W3 (dense,
 // (v m)^2, far larger than LDS) is streamed column block by column block into an LDS ring by three more waves
-// that never store and take the blocks in turn, so that every fetch has two sweep steps to arrive.
+// that never store to it: each holds its share of up to eight blocks in flight in registers, so that a fetch has
+// several sweep steps to arrive (a CU's vector-memory pipeline is in order: loads queue behind the store stream).
+// The same three waves form fvec while the compute waves write Gamma.
 //
 // Reference math: src/control/controller.rs:32-44 (Phi), :46-90 (Gamma), :92-93 (H), :96 and :125-127 (fvec).
 #include <utility>
@@ -27,9 +29,6 @@
 namespace mpcx {
 namespace {
 
-#ifndef WG_EXP
-#define WG_EXP 0
-#endif
 constexpr int kCompute = 256;            // threads that compute and store
 constexpr int kLoaders = 3;               // loader waves: each fetches every kLoaders-th column block of W3
 constexpr int kWgBlock = kCompute + 64 * kLoaders;
@@ -153,8 +152,7 @@ struct W3Loader {
         const int s = s0 + U;
         constexpr int SET = (U + 1) % NBR;
         double *dst = sW3 + ((v - 2 - s) & 1) * wcnt;
-        if (WG_EXP & 1) {
-        } else if (NB > 0) {
+        if (NB > 0) {
             w3_commit<SPB>(reg[SET], dst, n2, lw, ltid);
             w3_fetch<SPB>(reg[SET], block_of(s + 1 + NBR), n2, lw, ltid);
         } else if (s + 1 < v) {
@@ -201,7 +199,9 @@ __device__ __forceinline__ void w3_loader_run(const double *gW3, double *sW3, in
 template <int HM, int HR, int ITEMS, bool HELD>
 __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     extern __shared__ double lds[];
-#if (WG_EXP & 8)
+    // Diagnostic build (-DMPCX_WG_STAMPS, see tools/probe_phases.py): thread 0 records the 100 MHz wall clock at the
+    // phase boundaries into the caller's fvec buffer (v m >= 10 doubles per instance), and fvec itself is not computed.
+#ifdef MPCX_WG_STAMPS
     double *stampbuf = p.fvec + (long long)blockIdx.x * p.v * (HM ? HM : p.m);
     p.fvec = nullptr;
 #define STAMP(k) do { if (threadIdx.x == 0) stampbuf[k] = (double)wall_clock64(); } while (0)
@@ -546,7 +546,6 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                             else if (held && lastrow) out[i] = tabRow[(bb * HM + i) * HM + j];
                             out[i] += w3v[ic][i];
                         }
-                        if (WG_EXP & 2) { if (out[0] == 1.2345e-300) dst[0] = out[1] + out[HM - 1]; } else
                         if constexpr (HM % 2 == 0) {
 #pragma unroll
                             for (int i = 0; i < HM; i += 2) *(double2 *)(dst + i) = make_double2(out[i], out[i + 1]);

@@ -1,4 +1,4 @@
-"""Phase stamps of the workgroup QP kernel (needs a library built with -DWG_EXP=8; diagnostic, GPU only)."""
+"""Phase stamps of the workgroup QP kernel (needs a library built with -DMPCX_WG_STAMPS, e.g. tools/build_variant.sh stamps qp_wg.hip -DMPCX_WG_STAMPS, and MPCX_LIB pointing at it; diagnostic, GPU only)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

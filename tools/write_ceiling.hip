@@ -52,6 +52,21 @@ __global__ void tiled8_nt(double *p, size_t batch, int P, int TW) {
     for (int e = 0; e < P; ++e) { __builtin_nontemporal_store((double)e, q); q += TW; }
 }
 
+// tiled8 with occupancy capped by a dynamic LDS allocation (lds_bytes per 64-lane workgroup) and an optional stretch
+// of arithmetic before each store (spin FMAs), to mimic a kernel that computes what it stores
+__global__ void tiled8_occ(double *p, size_t batch, int P, int TW, int spin) {
+    extern __shared__ double pad[];
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double *q = p + (b / TW) * (size_t)P * TW + (b % TW);
+    double x = (double)threadIdx.x;
+    if (P < 0) pad[threadIdx.x] = x;  // keeps the allocation
+    for (int e = 0; e < P; ++e) {
+        for (int k = 0; k < spin; ++k) x = x * 1.0000001 + 0.5;
+        *q = x + (double)e; q += TW;
+    }
+}
+
 template <class F> float time_it(F f, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); f(); CK(hipDeviceSynchronize());
@@ -79,6 +94,14 @@ int main() {
             printf("tiled8 TW %4d block %3d : %7.1f GB/s\n", tw, blk, gb / ms * 1e3);
             ms = time_it([&] { tiled8_nt<<<batch / blk, blk>>>(p, batch, P, tw); }, 10);
             printf("tiled8_nt TW %4d block %3d : %7.1f GB/s\n", tw, blk, gb / ms * 1e3);
+        }
+        if (blk == 64) {
+            for (int ldsb : {0, 5 * 1024, 10 * 1024, 20 * 1024}) {  // 160 KB / ldsb workgroups (= waves) per CU
+                for (int spin : {0, 2, 8}) {
+                    ms = time_it([&] { hipLaunchKernelGGL(tiled8_occ, dim3(batch / 64), dim3(64), ldsb, 0, p, batch, P, 4096, spin); }, 10);
+                    printf("tiled8_occ TW 4096 lds %5d spin %d : %7.1f GB/s\n", ldsb, spin, gb / ms * 1e3);
+                }
+            }
         }
         ms = time_it([&] { fill16_nt<<<8192, blk>>>((double2 *)p, n / 2); }, 10);
         printf("fill16_nt grid   8192 block %3d : %7.1f GB/s\n", blk, gb / ms * 1e3);
