@@ -383,9 +383,8 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     //      the H sweep.  Workgroups that share a CU run the same phases for the same time and would stay in lockstep,
     //      all storing Gamma at once and all sweeping at once; every other resident workgroup therefore writes Gamma
     //      last, so that one workgroup's store stream overlaps the other's sweep.
-    //      Only where Gamma is the bulk of the bytes (f r >= 2 v m): with H as large as Gamma the sweep is a store
-    //      stream itself, and workgroups sweeping in step share their W3 blocks in L2. ----
-    const bool gamma_last = p.Gamma && p.H && FR >= 2 * VM && (blockIdx.x & 1);
+    //      Only where Gamma is at least as large as H (f r >= v m). ----
+    const bool gamma_last = p.Gamma && p.H && FR >= VM && (blockIdx.x & 1);
     auto write_gamma = [&]() {
         double *gG = p.Gamma + b * (long long)FR * VM;
         const int wave = tid >> 6, lane = tid & 63, nwaves = kCompute >> 6;
