@@ -22,6 +22,7 @@
 // The same three waves form fvec while the compute waves write Gamma.
 //
 // Reference math: src/control/controller.rs:32-44 (Phi), :46-90 (Gamma), :92-93 (H), :96 and :125-127 (fvec).
+#include <type_traits>
 #include <utility>
 
 #include "mpcx_internal.h"
@@ -282,30 +283,42 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                 for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = sAx[j];
             }
         }
-        for (int k = 0; k < f; ++k) {
-            const double *Wc = sW + (k & 1) * nW;
-            double *Wn = sW + ((k + 1) & 1) * nW;
-            const double *Pc = sP + (k & 1) * nP;
-            double *Pn = sP + ((k + 1) & 1) * nP;
-            if (kind >= 0) {
-                const double *op = (kind >= 2 ? Pc : Wc) + op_off;
-                double s = 0.0;
-                // unconditional loads (index clamped, coefficient zero past n): all issue together, one wait
+        // The dot product is as long as the smallest of 8, 12, 16 that holds n (shorter serial chain, fewer LDS reads),
+        // and runs as two partial sums.
+        auto recur = [&](auto width) {
+            constexpr int KC = decltype(width)::value;
+            for (int k = 0; k < f; ++k) {
+                const double *Wc = sW + (k & 1) * nW;
+                double *Wn = sW + ((k + 1) & 1) * nW;
+                const double *Pc = sP + (k & 1) * nP;
+                double *Pn = sP + ((k + 1) & 1) * nP;
+                if (kind >= 0) {
+                    const double *op = (kind >= 2 ? Pc : Wc) + op_off;
+                    double s0 = 0.0, s1 = 0.0;
+                    // unconditional loads (index clamped, coefficient zero past n): all issue together, one wait
 #pragma unroll
-                for (int j = 0; j < kCoef; ++j) s += coef[j] * op[(j < n ? j : n - 1) * op_stride];
-                if (kind == 0) {
-                    sG[out_off + k * r] = s;
-                } else if (kind == 1) {
-                    Wn[out_off] = s;
-                } else if (kind == 2) {
-                    Pn[out_off] = s;
-                    if (gPhi) gPhi[phi_off + k * r] = s;
-                } else {
-                    sSr[k * r + out_off] = s - sSr[k * r + out_off];
+                    for (int j = 0; j < KC; j += 2) {
+                        s0 += coef[j] * op[(j < n ? j : n - 1) * op_stride];
+                        s1 += coef[j + 1] * op[(j + 1 < n ? j + 1 : n - 1) * op_stride];
+                    }
+                    const double s = s0 + s1;
+                    if (kind == 0) {
+                        sG[out_off + k * r] = s;
+                    } else if (kind == 1) {
+                        Wn[out_off] = s;
+                    } else if (kind == 2) {
+                        Pn[out_off] = s;
+                        if (gPhi) gPhi[phi_off + k * r] = s;
+                    } else {
+                        sSr[k * r + out_off] = s - sSr[k * r + out_off];
+                    }
                 }
+                lds_barrier();
             }
-            lds_barrier();
-        }
+        };
+        if (n <= 8) recur(std::integral_constant<int, 8>{});
+        else if (n <= 12) recur(std::integral_constant<int, 12>{});
+        else recur(std::integral_constant<int, kCoef>{});
     } else {
         for (int k = 0; k < f; ++k) {
             const double *Wc = sW + (k & 1) * nW;
