@@ -386,6 +386,197 @@ __global__ __launch_bounds__(kGroupThreads) void closed_loop_group_kernel(LoopAr
 #undef IN
 }
 
+// A double moved across lanes by a data-parallel-primitive pattern (an ALU-speed exchange inside a row of 16 lanes;
+// CTRL: quad permutation 0x00..0xFF, row rotate right by k = 0x120 + k).  Every lane has a valid source lane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Register-resident variant of the group kernel for at most four inputs and f r <= 3 x 256 window rows: thread t owns
+// rows t, t + 256, t + 512 of the window, with their rows of Phi (n values each) and their columns of the first m gain
+// rows in registers for the whole loop.  A step is then: read the state (LDS broadcast), s_c = ref_c - Phi_c x,
+// partial u = K s over the thread's rows, a wavefront reduction, one barrier, and the propagation by n threads that
+// each add up the four wavefronts' partial sums themselves; a second barrier publishes the new state.  Nothing of
+// Phi or the gain lives in LDS (about 10 KB per instance instead of 80), so several workgroups share a CU and hide
+// one another's barriers.  The arithmetic order of the reference is kept: s first, then gain s.
+template <int NP, int RPT>
+__global__ __launch_bounds__(kGroupThreads, NP >= 8 ? 2 : 3) void closed_loop_rows_kernel(LoopArgs p) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long b = blockIdx.x;
+    const int n = p.n, m = p.m, r = p.r, F = p.f, FR = F * r, VM = p.v * m;
+    const long long W = p.W, tile = b / W, li = b - tile * W, T = p.T;
+    const long long L = T + F, ER = (long long)r * L;
+    const int RC = F + kChunk;
+#define IN(ptr, E, e) ((ptr)[tile * (long long)(E) * W + (long long)(e) * W + li])
+    double *sA = lds, *sB = sA + n * n, *sC = sB + n * m, *sx = sC + r * n, *sPart = sx + 2 * n;
+    double *sOut = sPart + 2 * kGroupWaves * 4;
+    const int out_per_step = n + m + r;
+    double *sRing = sOut + kChunk * out_per_step;  // (tau % RC) * r + a
+    for (int e = tid; e < n * n; e += kGroupThreads) sA[e] = IN(p.A, n * n, e);
+    for (int e = tid; e < n * m; e += kGroupThreads) sB[e] = IN(p.B, n * m, e);
+    for (int e = tid; e < r * n; e += kGroupThreads) sC[e] = IN(p.C, r * n, e);
+    double phi[RPT][NP], kk[RPT][4];
+    int rowc[RPT];
+    bool live[RPT];
+#pragma unroll
+    for (int g = 0; g < RPT; ++g) {
+        const int c = tid + g * kGroupThreads;
+        live[g] = c < FR;
+        rowc[g] = live[g] ? c : FR - 1;
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            phi[g][j] = (live[g] && j < n) ? IN(p.Phi, (long long)FR * n, (long long)(j < n ? j : 0) * FR + rowc[g]) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            kk[g][k] = (live[g] && k < m) ? IN(p.gain, (long long)VM * FR, (long long)rowc[g] * VM + (k < m ? k : 0)) : 0.0;
+    }
+    const long long EX = (long long)n * (T + 1), EY = (long long)r * T, EU = (long long)m * T;
+    if (tid < n) {
+        const double x0 = IN(p.x0, n, tid);
+        sx[tid] = x0;
+        if (p.X) IN(p.X, EX, tid) = x0;
+    }
+    // reference: element (a, tau) at rbase[tau * rstep] for lane a of the last wavefront
+    const bool loader = wv == kGroupWaves - 1;
+    const int la = lane < r ? lane : 0;
+    const double *rbase = p.ref_shared ? p.ref + la : &IN(p.ref, ER, la);
+    const long long rstep = p.ref_shared ? (long long)r : (long long)r * W;
+    double pre[kChunk];
+    if (loader) {
+        const long long first = (kChunk + F - 1 < L) ? kChunk + F - 1 : L;
+        for (long long tau = 0; tau < first; ++tau)
+            if (lane < r) sRing[(int)(tau % RC) * r + lane] = rbase[tau * rstep];
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {  // branch-free, clamped to valid (unused) addresses
+            const long long tau = kChunk + F - 1 + q;
+            pre[q] = rbase[(tau < L ? tau : L - 1) * rstep];
+        }
+    }
+    __syncthreads();
+    for (long long t0 = 0; t0 < T; t0 += kChunk) {
+        const int steps = (int)((T - t0 < kChunk) ? T - t0 : kChunk);
+        if (loader && t0 > 0) {
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                const long long tau = t0 + F - 1 + q;
+                if (lane < r) sRing[(int)(tau % RC) * r + lane] = pre[q];
+            }
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                const long long tau = t0 + kChunk + F - 1 + q;
+                pre[q] = rbase[(tau < L ? tau : L - 1) * rstep];
+            }
+        }
+        lds_barrier();
+        for (int q = 0; q < steps; ++q) {
+            const long long t = t0 + q;
+            const int tmod = (int)(t % RC);
+            const double *xc = sx + (t & 1) * n;
+            double *xn = sx + ((t + 1) & 1) * n;
+            double *part = sPart + (t & 1) * kGroupWaves * 4;
+            double *out = sOut + q * out_per_step;  // [x_{t+1} (n) | u_t (m) | y_t (r)]
+            double x[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) x[j] = xc[j < n ? j : n - 1];  // phi is zero past n
+            double uacc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int g = 0; g < RPT; ++g) {
+                // row c = i r + a of the window is column t + i, row a of the trajectory: ring index (t mod RC) r + c
+                int ri = tmod * r + rowc[g];
+                if (ri >= RC * r) ri -= RC * r;
+                const double refv = sRing[ri];
+                double ox = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) ox += phi[g][j] * x[j];
+                const double sv = live[g] ? refv - ox : 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) uacc[k] += kk[g][k] * sv;
+            }
+            // Wavefront reduction of the four sums as a reduce-scatter: after two exchange levels a lane carries one of the
+            // four sums for its group of four lanes (7 exchanges of a double instead of 24, five of them register moves).  Lane l ends up with sum
+            // 2 (l & 1) + ((l >> 1) & 1).
+            {
+                const bool b0 = lane & 1, b1 = lane & 2;
+                const double s0 = b0 ? uacc[0] : uacc[2], s1 = b0 ? uacc[1] : uacc[3];
+                double k0 = b0 ? uacc[2] : uacc[0], k1 = b0 ? uacc[3] : uacc[1];
+                k0 += dpp_f64<0xB1>(s0);  // lane ^ 1 (quad permutation 1,0,3,2)
+                k1 += dpp_f64<0xB1>(s1);
+                double mine = (b1 ? k1 : k0) + dpp_f64<0x4E>(b1 ? k0 : k1);  // lane ^ 2 (2,3,0,1)
+                mine += dpp_f64<0x124>(mine);  // rotate by 4 within the row of 16 lanes
+                mine += dpp_f64<0x128>(mine);  // rotate by 8: every lane of a row now holds its row's sum
+                mine += __shfl_xor(mine, 16);
+                mine += __shfl_xor(mine, 32);
+                if (lane < 4) part[wv * 4 + 2 * (lane & 1) + ((lane >> 1) & 1)] = mine;
+            }
+            lds_barrier();
+            if (tid < n) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) sacc += sA[(j < n ? j : 0) * n + tid] * (j < n ? x[j] : 0.0);
+                double qv = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double u = 0.0;
+#pragma unroll
+                    for (int w = 0; w < kGroupWaves; ++w) u += part[w * 4 + k];
+                    qv += (k < m ? sB[k * n + tid] : 0.0) * u;
+                }
+                sacc += qv;
+                xn[tid] = sacc;
+                out[tid] = sacc;
+            } else if (tid >= kWave && tid < kWave + r) {  // outputs on the second wavefront
+                const int a = tid - kWave;
+                double y = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) y += sC[(j < n ? j : 0) * r + a] * (j < n ? x[j] : 0.0);
+                out[n + m + a] = y;
+            } else if (tid >= 2 * kWave && tid < 2 * kWave + m) {  // the move itself on the third
+                const int k = tid - 2 * kWave;
+                double u = 0.0;
+#pragma unroll
+                for (int w = 0; w < kGroupWaves; ++w) u += part[w * 4 + k];
+                out[n + k] = u;
+            }
+            lds_barrier();
+        }
+        // flush the chunk: X columns t0+1 .. t0+steps are contiguous per instance, likewise U and Y
+        if (!loader) {
+            constexpr int kFlush = kGroupThreads - kWave;
+            if (p.X)
+                for (int e = tid; e < steps * n; e += kFlush) IN(p.X, EX, (t0 + 1) * n + e) = sOut[(e / n) * out_per_step + (e % n)];
+            if (p.U)
+                for (int e = tid; e < steps * m; e += kFlush) IN(p.U, EU, t0 * m + e) = sOut[(e / m) * out_per_step + n + (e % m)];
+            if (p.Y)
+                for (int e = tid; e < steps * r; e += kFlush) IN(p.Y, EY, t0 * r + e) = sOut[(e / r) * out_per_step + n + m + (e % r)];
+        }
+        lds_barrier();
+    }
+#undef IN
+}
+
+size_t rows_lds_bytes(const LoopArgs &a) {
+    size_t d = (size_t)a.n * a.n + (size_t)a.n * a.m + (size_t)a.r * a.n + 2 * a.n + 2 * kGroupWaves * 4 +
+               (size_t)kChunk * (a.n + a.m + a.r) + (size_t)(a.f + kChunk) * a.r;
+    return d * sizeof(double);
+}
+
+template <int NP, int RPT>
+int launch_rows_inst(const LoopArgs &a, hipStream_t s) {
+    const size_t lds_bytes = rows_lds_bytes(a);
+    if (lds_bytes > 64 * 1024) return MPCX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((closed_loop_rows_kernel<NP, RPT>), dim3((unsigned)a.batch), dim3(kGroupThreads), lds_bytes, s, a);
+    return (int)hipGetLastError();
+}
+template <int NP>
+int launch_rows_np(const LoopArgs &a, hipStream_t s) {
+    const int rpt = (a.f * a.r + kGroupThreads - 1) / kGroupThreads;
+    return rpt <= 1 ? launch_rows_inst<NP, 1>(a, s) : rpt == 2 ? launch_rows_inst<NP, 2>(a, s) : launch_rows_inst<NP, 3>(a, s);
+}
+
 size_t group_lds_bytes(const LoopArgs &a) {
     const size_t fr = (size_t)a.f * a.r;
     size_t d = (size_t)a.n * a.n + (size_t)a.n * a.m + (size_t)a.r * a.n + fr * a.n + fr * a.m + 2 * a.n + fr + a.m +
@@ -409,6 +600,13 @@ int launch_closed_loop_lane(const LoopArgs &a, hipStream_t s) {
 int launch_closed_loop_group(const LoopArgs &a, hipStream_t s) {
     if (a.n > kWave || a.m > kWave || a.r > kWave) return MPCX_ERR_UNSUPPORTED;
     if (a.batch > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    // few inputs and a window of at most 768 rows: Phi and the gain rows live in registers
+    if (a.m <= 4 && a.n <= 16 && (long long)a.f * a.r <= 3 * kGroupThreads && rows_lds_bytes(a) <= 64 * 1024) {
+        if (a.n <= 4) return launch_rows_np<4>(a, s);
+        if (a.n <= 8) return launch_rows_np<8>(a, s);
+        if (a.n <= 12) return launch_rows_np<12>(a, s);
+        return launch_rows_np<16>(a, s);
+    }
     const size_t lds_bytes = group_lds_bytes(a);
     if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
     if (lds_bytes > 64 * 1024) {
