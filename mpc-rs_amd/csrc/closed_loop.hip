@@ -386,15 +386,6 @@ __global__ __launch_bounds__(kGroupThreads) void closed_loop_group_kernel(LoopAr
 #undef IN
 }
 
-// A double moved across lanes by a data-parallel-primitive pattern (an ALU-speed exchange inside a row of 16 lanes;
-// CTRL: quad permutation 0x00..0xFF, row rotate right by k = 0x120 + k).  Every lane has a valid source lane.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
 // Register-resident variant of the group kernel for at most four inputs and f r <= 3 x 256 window rows: thread t owns
 // rows t, t + 256, t + 512 of the window, with their rows of Phi (n values each) and their columns of the first m gain
 // rows in registers for the whole loop.  A step is then: read the state (LDS broadcast), s_c = ref_c - Phi_c x,

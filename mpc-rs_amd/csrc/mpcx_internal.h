@@ -81,6 +81,16 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// A double moved across lanes by a data-parallel-primitive pattern (an ALU-speed exchange inside a row of 16 lanes;
+// CTRL: quad permutation 0x00..0xFF, row rotate right by k = 0x120 + k).  Every lane has a valid source lane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    // (mov_dpp: no "old" operand to initialise, one instruction per half)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // Index of element e of instance b in an array with E elements per instance and interleave width W.
 __host__ __device__ inline long long elem_index(long long b, long long e, long long E, long long W) {
     const long long tile = b / W;
