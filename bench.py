@@ -313,7 +313,7 @@ def main():
         if args.op in ("solve", "gain", "loop", "plants"):
             res["check"]["singular_instances"] = int((info != 0).sum().item())
         if world == 1 and not args.no_cpu_baseline and args.op in ("qp", "rollout"):
-            res["cpu_baseline"] = _cpu_baseline(args, d, n, m, r, f, v, T, unit)
+            res["cpu_baseline"] = _cpu_baseline(args, d, n, m, r, f, v, T, unit, outs, il, count)
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
@@ -332,10 +332,11 @@ def _traffic(args, per_gpu):
         return None
 
 
-def _cpu_baseline(args, d, n, m, r, f, v, T, unit):
+def _cpu_baseline(args, d, n, m, r, f, v, T, unit, outs, il, count):
     """The CPU oracle (a port that keeps the reference's algorithmic structure) on a bounded sample of the same
-    workload, all host cores of this box's share, timed around the C call only."""
-    from mpc_rs_amd import synth
+    workload, all host cores of this box's share, timed around the C call only.  The outputs it produces for the
+    first instances are also held against what the GPU left in HBM (`parity`: relative Frobenius error per output)."""
+    from mpc_rs_amd import layout as L, synth
     from oracle import oracle_ffi as orc
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
     est = {"two_mass": 1.2e4, "msd": 1.5e4, "quadrotor": 8.0, "long": 0.4}[args.workload] * cores  # builds/s, rough
@@ -346,14 +347,42 @@ def _cpu_baseline(args, d, n, m, r, f, v, T, unit):
     tm = {}
     if args.op == "qp":
         w4 = synth.dense_w4(d["Q"], f)
-        orc.qp_build_batch(d["A"][sl], d["B"][sl], d["C"][sl], d["W3"], w4, d["x0"][sl], d["ref"][sl], f, v,
-                           threads=cores, timing=tm)
+        want, _ = orc.qp_build_batch(d["A"][sl], d["B"][sl], d["C"][sl], d["W3"], w4, d["x0"][sl], d["ref"][sl], f, v,
+                                     threads=cores, timing=tm)
+        shapes = {"Phi": (f * r, n), "Gamma": (f * r, v * m), "H": (v * m, v * m), "fvec": (v * m, 1)}
         secs = tm["seconds"]
     else:
-        orc.rollout_batch(d["A"][sl], d["B"][sl], d["C"][sl], d["x0"][sl], d["U"], threads=cores, timing=tm)
+        X, Y, _ = orc.rollout_batch(d["A"][sl], d["B"][sl], d["C"][sl], d["x0"][sl], d["U"], threads=cores, timing=tm)
+        want = {"X": X, "Y": Y}
+        shapes = {"X": (n, T + 1), "Y": (r, T)}
         secs = tm["seconds"]
     res = {"value": sample / secs, "unit": unit, "cores": cores, "kind": "port",
            "sample": f"first {sample} instances of the same workload, {secs:.1f} s, OpenMP over instances"}
+    # parity of what the timed GPU steps left in HBM with the port's outputs, on the first instances of the shard
+    w = L.resolve_width(count, il)
+    npar = min(sample, count, 4096 if (w == 1 or w >= count) else w)  # tiled layouts: within the first tile
+    par = {}
+    for k, (rows, cols) in shapes.items():
+        E = rows * cols
+        if w >= count:  # W = batch: the first instances are the first entries of every element plane
+            got = outs[k].view(E, count)[:, :npar].cpu().numpy().T.reshape(npar, cols, rows).transpose(0, 2, 1)
+        else:
+            got = L.unpack(outs[k][: -(-npar // w) * w * E].cpu().numpy(), npar, rows, cols, il)
+        ref = want[k][:npar].reshape(npar, rows, cols)
+        num = np.sqrt(((got - ref) ** 2).reshape(npar, -1).sum(axis=1))
+        den = np.maximum(np.sqrt((ref ** 2).reshape(npar, -1).sum(axis=1)), 1e-300)
+        par[k] = float((num / den).max())
+    res["parity"] = {"instances": npar, "max_rel_frobenius_vs_port": par, "tolerance": 1e-10}
+    # one core of the same port, on a sample a sixteenth the size
+    one = max(1, sample // 16)
+    tm1 = {}
+    if args.op == "qp":
+        orc.qp_build_batch(d["A"][:one], d["B"][:one], d["C"][:one], d["W3"], w4, d["x0"][:one], d["ref"][:one], f, v,
+                           threads=1, timing=tm1)
+    else:
+        orc.rollout_batch(d["A"][:one], d["B"][:one], d["C"][:one], d["x0"][:one], d["U"], threads=1, timing=tm1)
+    res["single_core"] = {"value": one / tm1["seconds"], "unit": unit, "cores": 1,
+                          "sample": f"first {one} instances, {tm1['seconds']:.1f} s"}
     if args.op == "qp":
         # second line: a CPU implementation written for speed (O(f) recurrences, block weights, no heap traffic), so
         # that the GPU/CPU ratio is not inflated by the reference's own loop structure
