@@ -130,46 +130,65 @@ def test_qp_build_full_size(ctx, torch_dev, name):
             {"A": (n, n), "B": (n, m), "C": (r, n), "x0": (n, 1), "ref": (FR, 1)}.items()}
     full.update({k: _view(outs[k], batch, *shapes[k], il) for k in outs})
     full["Y"] = _view(Y, batch, r, T, il)
-    worst = {}
-
-    def note(key, e):
-        worst[key] = max(worst.get(key, 0.0), e)
-
     step = CHUNK[name]
-    for lo in range(0, batch, step):
-        sl = slice(lo, min(lo + step, batch))
-        A, B, Cm, x0, ref = (full[k][sl] for k in ("A", "B", "C", "x0", "ref"))
-        Phi, Gam, H, fv = (full[k][sl].contiguous() for k in ("Phi", "Gamma", "H", "fvec"))
-        b = Phi.shape[0]
-        # Phi: first block and the block recurrence
-        note("Phi[0] = C A", _rel(Phi[:, :r], Cm @ A))
-        if f > 1:
-            note("Phi[i+1] = Phi[i] A", _rel(Phi[:, r:], Phi[:, :-r] @ A))
-        # Gamma: Markov blocks in block column 0 (or the running sum when v = 1)
-        G = torch.cat([Cm @ B, Phi[:, :-r] @ B], dim=1)                              # (b, f r, m): G_0 .. G_{f-1}
-        S = torch.cumsum(G.view(b, f, r, m), dim=1).reshape(b, FR, m)
-        if v > 1:
-            note("Gamma[:, 0] = Markov blocks", _rel(Gam[:, :, :m], G))
-        for k in range(1, v - 1):   # shifted copies, exact zeros above
-            col = Gam[:, :, k * m:(k + 1) * m]
-            assert bool((col[:, :k * r] == 0).all()), f"{name}: Gamma block column {k} is not zero above the diagonal"
-            note("Gamma Toeplitz shift", _rel(col[:, k * r:], Gam[:, :FR - k * r, :m]))
-        last = Gam[:, :, (v - 1) * m:]
-        assert bool((last[:, :(v - 1) * r] == 0).all()), f"{name}: last Gamma block column is not zero above the diagonal"
-        note("Gamma last column = running sum", _rel(last[:, (v - 1) * r:], S[:, :FR - (v - 1) * r]))
-        # H and fvec from the library's own Gamma and Phi
-        QG = torch.einsum("pq,bfqc->bfpc", Q, Gam.view(b, f, r, VM)).reshape(b, FR, VM)
-        note("H = Gamma^T Qbar Gamma + W3", _rel(H, Gam.transpose(1, 2) @ QG + W3))
-        s = Phi @ x0 - ref
-        z = torch.einsum("pq,bfq->bfp", Q, s.view(b, f, r)).reshape(b, FR, 1)
-        note("fvec = Gamma^T Qbar (Phi x0 - ref)", _rel(fv, Gam.transpose(1, 2) @ z))
-        # prediction consistency with the rollout kernel
-        pred = Phi @ x0 + Gam @ useq[sl].unsqueeze(2)                                  # (b, f r, 1): y_1 .. y_f
-        yy = full["Y"][sl][:, :, 1:].transpose(1, 2).reshape(b, FR, 1)
-        note("Phi x0 + Gamma u = rollout outputs", _rel(pred, yy))
-        del QG, G, S
+
+    def sweep(first=0):
+        worst = {}
+
+        def note(key, e):
+            worst[key] = max(worst.get(key, 0.0), e)
+
+        for lo in range(first, batch, step):
+            sl = slice(lo, min(lo + step, batch))
+            A, B, Cm, x0, ref = (full[k][sl] for k in ("A", "B", "C", "x0", "ref"))
+            Phi, Gam, H, fv = (full[k][sl].contiguous() for k in ("Phi", "Gamma", "H", "fvec"))
+            b = Phi.shape[0]
+            # Phi: first block and the block recurrence
+            note("Phi[0] = C A", _rel(Phi[:, :r], Cm @ A))
+            if f > 1:
+                note("Phi[i+1] = Phi[i] A", _rel(Phi[:, r:], Phi[:, :-r] @ A))
+            # Gamma: Markov blocks in block column 0 (or the running sum when v = 1)
+            G = torch.cat([Cm @ B, Phi[:, :-r] @ B], dim=1)                              # (b, f r, m): G_0 .. G_{f-1}
+            S = torch.cumsum(G.view(b, f, r, m), dim=1).reshape(b, FR, m)
+            if v > 1:
+                note("Gamma[:, 0] = Markov blocks", _rel(Gam[:, :, :m], G))
+            for k in range(1, v - 1):   # shifted copies, exact zeros above
+                col = Gam[:, :, k * m:(k + 1) * m]
+                assert bool((col[:, :k * r] == 0).all()), f"{name}: Gamma block column {k} is not zero above the diagonal"
+                note("Gamma Toeplitz shift", _rel(col[:, k * r:], Gam[:, :FR - k * r, :m]))
+            last = Gam[:, :, (v - 1) * m:]
+            assert bool((last[:, :(v - 1) * r] == 0).all()), f"{name}: last Gamma block column is not zero above the diagonal"
+            note("Gamma last column = running sum", _rel(last[:, (v - 1) * r:], S[:, :FR - (v - 1) * r]))
+            # H and fvec from the library's own Gamma and Phi
+            QG = torch.einsum("pq,bfqc->bfpc", Q, Gam.view(b, f, r, VM)).reshape(b, FR, VM)
+            note("H = Gamma^T Qbar Gamma + W3", _rel(H, Gam.transpose(1, 2) @ QG + W3))
+            s = Phi @ x0 - ref
+            z = torch.einsum("pq,bfq->bfp", Q, s.view(b, f, r)).reshape(b, FR, 1)
+            note("fvec = Gamma^T Qbar (Phi x0 - ref)", _rel(fv, Gam.transpose(1, 2) @ z))
+            # prediction consistency with the rollout kernel
+            pred = Phi @ x0 + Gam @ useq[sl].unsqueeze(2)                                  # (b, f r, 1): y_1 .. y_f
+            yy = full["Y"][sl][:, :, 1:].transpose(1, 2).reshape(b, FR, 1)
+            note("Phi x0 + Gamma u = rollout outputs", _rel(pred, yy))
+            del QG, G, S
+        return worst
+
+    worst = sweep()
     bad = {k: e for k, e in worst.items() if not e <= RTOL}
     assert not bad, f"{name} (batch {batch}): {bad}"
+
+    if name == "msd":
+        # negative control: one element of one instance off by 1e-6 (relative) must trip each property that covers it
+        saved = {k: full[k][batch - 1].clone() for k in ("Phi", "Gamma", "H", "fvec")}
+        full["Phi"][batch - 1, 5, 1] *= 1.0 + 1e-6
+        full["Gamma"][batch - 1, 7, 2] *= 1.0 + 1e-6
+        full["H"][batch - 1, 3, 5] *= 1.0 + 1e-6
+        full["fvec"][batch - 1, 4, 0] *= 1.0 + 1e-6
+        tripped = sweep(first=(batch - 1) // step * step)
+        for key in ("Phi[i+1] = Phi[i] A", "Gamma Toeplitz shift", "H = Gamma^T Qbar Gamma + W3",
+                    "fvec = Gamma^T Qbar (Phi x0 - ref)", "Phi x0 + Gamma u = rollout outputs"):
+            assert tripped[key] > RTOL, f"the property '{key}' did not notice a perturbed element"
+        for k, val in saved.items():
+            full[k][batch - 1] = val
 
     # a spread of instances against the CPU oracle, element by element
     idx = _sample_indices(batch, il, ORACLE_SAMPLES[name], seed=5)
@@ -233,3 +252,79 @@ def test_rollout_full_size(ctx, torch_dev, name):
         num = np.linalg.norm((got - want).reshape(len(idx), -1), axis=1)
         den = np.maximum(np.linalg.norm(want.reshape(len(idx), -1), axis=1), 1e-300)
         assert float((num / den).max()) <= RTOL, f"{name}: {k} differs from the oracle: {float((num / den).max()):.3e}"
+
+
+@pytest.mark.parametrize("name", ["msd", "two_mass"])
+def test_gain_solve_loop_full_size(ctx, torch_dev, name):
+    """Device chain build -> gain / solve -> closed loop at the full batch (controller.rs:93-96, :117-135,
+    main.rs:51-71).  The solves are held to a backward-error bound (independent of cond(H)):
+    ||H X - R|| <= 1e-10 (||H|| ||X|| + ||R||); the loop to its own recurrences, evaluated for every instance."""
+    torch, dev = torch_dev
+    from mpc_rs_amd import ffi, layout as L, synth
+
+    batch = FULL[name]
+    d = synth.make_batch(name, batch)
+    n, m, r, f, v, T = d["n"], d["m"], d["r"], d["f"], d["v"], d["T"]
+    FR, VM = f * r, v * m
+    il = 4096
+    bufs = _resident(torch, dev, d, il, batch)
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def out(elems):
+        return torch.full((L.array_elems(batch, il, elems),), float("nan"), dtype=torch.float64, device=dev)
+    qp = {"Phi": out(FR * n), "Gamma": out(FR * VM), "H": out(VM * VM), "fvec": out(VM)}
+    dims = ffi.make_dims(n, m, r, f, v, batch, T, il, u_shared=1)
+    ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["W3"].data_ptr(),
+                     bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(), qp["Phi"].data_ptr(),
+                     qp["Gamma"].data_ptr(), qp["H"].data_ptr(), qp["fvec"].data_ptr(), sp)
+    info_g = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    info_s = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    gain, useq = out(VM * FR), out(VM)
+    ctx.qp_gain_dev(dims, qp["H"].data_ptr(), qp["Gamma"].data_ptr(), bufs["Q"].data_ptr(), gain.data_ptr(),
+                    info_g.data_ptr(), sp)
+    ctx.qp_solve_dev(dims, qp["H"].data_ptr(), qp["fvec"].data_ptr(), useq.data_ptr(), info_s.data_ptr(), sp)
+    pulse = np.zeros((r, T + f))
+    pulse[:, : (T + f) // 3] = 1.0
+    pulse[:, 2 * (T + f) // 3:] = 1.0                                                   # the shape of trajectory.rs:4-8
+    traj = torch.from_numpy(L.colmajor(pulse)).to(dev)
+    X, U, Y = out(n * (T + 1)), out(m * T), out(r * T)
+    ctx.closed_loop_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["x0"].data_ptr(),
+                        qp["Phi"].data_ptr(), gain.data_ptr(), traj.data_ptr(), X.data_ptr(), U.data_ptr(), Y.data_ptr(), sp)
+    torch.cuda.synchronize()
+    assert int((info_g != 0).sum()) == 0 and int((info_s != 0).sum()) == 0, "an instance was flagged singular"
+
+    Q = bufs["Q"].view(r, r).t()
+    A, B, Cm, x0 = (_view(bufs[k], batch, *s, il) for k, s in
+                    {"A": (n, n), "B": (n, m), "C": (r, n), "x0": (n, 1)}.items())
+    Phi, Gam, H, fv = (_view(qp[k], batch, *s, il) for k, s in
+                       {"Phi": (FR, n), "Gamma": (FR, VM), "H": (VM, VM), "fvec": (VM, 1)}.items())
+    K, us = _view(gain, batch, VM, FR, il), _view(useq, batch, VM, 1, il)
+    Xv, Uv, Yv = _view(X, batch, n, T + 1, il), _view(U, batch, m, T, il), _view(Y, batch, r, T, il)
+    ref_t = traj.view(T + f, r)                                                          # row t = reference at step t
+    win = torch.stack([ref_t[t:t + f].reshape(-1) for t in range(T)], dim=1)             # (f r, T): window of step t
+    fro = lambda a: torch.linalg.vector_norm(a.reshape(a.shape[0], -1), dim=1)
+    worst = {}
+
+    def note(key, e):
+        worst[key] = max(worst.get(key, 0.0), float(e))
+
+    step = CHUNK[name]
+    for lo in range(0, batch, step):
+        sl = slice(lo, min(lo + step, batch))
+        h, g, k_, u_ = H[sl].contiguous(), Gam[sl].contiguous(), K[sl].contiguous(), us[sl].contiguous()
+        b = h.shape[0]
+        rhs = torch.einsum("bfqc,qp->bcfp", g.view(b, f, r, VM), Q).reshape(b, VM, FR)   # Gamma^T blockdiag(Q)
+        note("H gain = Gamma^T W4", ((fro(h @ k_ - rhs)) / (fro(h) * fro(k_) + fro(rhs))).max())
+        note("H u = -fvec", ((fro(h @ u_ + fv[sl])) / (fro(h) * fro(u_) + fro(fv[sl]))).max())
+        xs, uu = Xv[sl].contiguous(), Uv[sl].contiguous()
+        assert bool((xs[:, :, :1] == x0[sl]).all())
+        # u_t = first m entries of gain (window_t - Phi x_t)   (controller.rs:125-132)
+        s = win.unsqueeze(0) - Phi[sl] @ xs[:, :, :T]                                     # (b, f r, T)
+        u_want = k_[:, :m, :] @ s
+        den = (fro(k_[:, :m, :]) * fro(s)).clamp_min(1e-300)                              # scale of the products summed
+        note("u = gain (ref - Phi x)", (fro(uu - u_want) / den).max())
+        nxt = A[sl] @ xs[:, :, :T] + B[sl] @ uu
+        note("x+ = A x + B u", (fro(xs[:, :, 1:] - nxt) / fro(xs).clamp_min(1e-300)).max())
+        note("y = C x", _rel(Yv[sl], Cm[sl] @ xs[:, :, :T]))
+    bad = {k: e for k, e in worst.items() if not e <= RTOL}
+    assert not bad, f"{name} (batch {batch}): {bad}"
