@@ -18,6 +18,8 @@ struct mpcx_ctx {
     void *aux;           // I - Ac dt of the general discretisation
     size_t aux_bytes;
     void *stat_scratch;  // partial records of the stats reduction + one result record
+    void *w3win;         // band structure of W3, measured on the device by every build call of the workgroup kernels
+    size_t w3win_bytes;
     char err[512];
 };
 
@@ -147,6 +149,8 @@ int mpcx_create(mpcx_ctx **out, int device_id) {
     ctx->aux = nullptr;
     ctx->aux_bytes = 0;
     ctx->stat_scratch = nullptr;
+    ctx->w3win = nullptr;
+    ctx->w3win_bytes = 0;
     ctx->err[0] = 0;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -171,6 +175,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->lu_work) (void)hipFree(ctx->lu_work);
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->stat_scratch) (void)hipFree(ctx->stat_scratch);
+    if (ctx->w3win) (void)hipFree(ctx->w3win);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -203,6 +208,16 @@ int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, co
     hipStream_t s = (hipStream_t)stream;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    a.w3win = nullptr;
+    a.w3win_bytes = 0;
+    if (H) {  // where the workgroup kernels measure the band structure of W3
+        if (!ctx->w3win) {
+            HIP_TRY(ctx, hipMalloc(&ctx->w3win, 256));
+            ctx->w3win_bytes = 256;
+        }
+        a.w3win = ctx->w3win;
+        a.w3win_bytes = ctx->w3win_bytes;
+    }
     if (d->hessian_algo != MPCX_HESSIAN_AUTO && d->hessian_algo != MPCX_HESSIAN_CONTRACT &&
         d->hessian_algo != MPCX_HESSIAN_STRUCTURED)
         return fail(ctx, MPCX_ERR_DIMS, "unknown hessian_algo %d", d->hessian_algo);

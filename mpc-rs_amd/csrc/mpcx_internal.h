@@ -16,6 +16,9 @@ struct QpArgs {
     long long batch, W;
     int n, m, r, f, v;
     int weights_mode;
+    // two ints of device scratch in which the workgroup kernels measure the band structure of W3, or null
+    void *w3win;
+    size_t w3win_bytes;
 };
 
 struct RolloutArgs {

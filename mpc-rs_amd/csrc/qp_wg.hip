@@ -22,6 +22,8 @@
 // The same three waves form fvec while the compute waves write Gamma.
 //
 // Reference math: src/control/controller.rs:32-44 (Phi), :46-90 (Gamma), :92-93 (H), :96 and :125-127 (fvec).
+#include <limits.h>
+
 #include <type_traits>
 #include <utility>
 
@@ -37,7 +39,7 @@ constexpr int kCoef = 16;                // recurrence coefficients a thread kee
 
 struct WgLds {
     // offsets in doubles into the dynamic LDS buffer
-    int G, S, QG, QS, A, B, C, x0, Q, Wst, Pst, Sr, Z, Hp, W3r, Tab, total;
+    int G, S, QG, QS, A, B, C, x0, Q, Wst, Pst, Sr, Z, Pow, Hp, W3r, Tab, total;
 };
 
 // G, S, QG, QS live for the whole kernel.  The inputs, the recurrence states and z are dead once fvec is out, and
@@ -60,6 +62,7 @@ __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v
     L.Pst = o; o += 2 * r * n;   // Phi state, ping-pong
     L.Sr = o; o += fr;           // ref, then Phi x0 - ref
     L.Z = o; o += fr;            // Q (Phi x0 - ref)
+    L.Pow = o; o += 3 * n * n + 3 * r * n + 4 * n;  // strided recurrences: A^2..A^4, C A..C A^3, A x0..A^4 x0
     const int end1 = o;
     o = u;
     L.Hp = o; o += 2 * v * m * m;   // column block of H (without W3), ping-pong: [slot][i*m + j][a]
@@ -102,27 +105,76 @@ __device__ __forceinline__ unsigned opaque(unsigned x) {  // x unchanged, but no
     asm volatile("" : "+v"(x));
     return x;
 }
+// The part of one column block of W3 that the sweep has to fetch: rows [row0, row0 + 2 wp) of each of its m columns
+// (n2 = m wp 16-byte pairs).  W3 as the reference builds it (W1^T W2 W1, controller.rs:149-177) is block
+// tridiagonal, so most of a column block is exact zeros.  w3_band_kernel measures how far the non-zeros of any column
+// block bb reach above and below row bb m; the loader then moves, for block bb, only a window of fixed height that
+// covers that reach for block bb and for block bb + 2 (the previous occupant of the ring slot, whose non-zeros the
+// window must overwrite): the rest of the slot already holds zeros.  A dense W3 gives the full block as window.
+// magic = floor(2^32 / wp) + 1 turns the division of a pair index (< 2^16) by wp (< 2^16) into a multiply-high.
+struct W3Win {
+    int row0, wp, n2;
+    unsigned magic;
+};
+struct W3Band {  // wave-uniform, set up once per loader wave
+    int up, wp, m, VM;  // reach above row bb m (may be negative), window height in pairs
+    unsigned magic;
+    bool full;          // the window is the whole column block
+    __device__ __forceinline__ W3Win window(int bb) const {
+        int r0 = (bb * m - up) & ~1;
+        const int top = VM - 2 * wp;
+        r0 = r0 < 0 ? 0 : (r0 > top ? top : r0);
+        W3Win w;
+        w.row0 = full ? 0 : r0; w.wp = wp; w.n2 = m * wp; w.magic = magic;
+        return w;
+    }
+};
+// reach[0], reach[1]: largest (bb m - first non-zero row) and (one past the last non-zero row - bb m) over the column
+// blocks of W3, INT_MIN where no block has a non-zero; null: no measurement, the window is the whole block.
+__device__ __forceinline__ W3Band w3_band_setup(const int *reach, int v, int m) {
+    W3Band b;
+    b.m = m; b.VM = v * m;
+    int up = 0, down = 0;
+    bool full = true;
+    if (reach) {
+        up = reach[0]; down = reach[1];
+        if (up == INT_MIN) { up = 0; down = 0; }
+        full = false;
+    }
+    int span = (up + down + 2 * m + 2) & ~1;  // both blocks' reach, and one row lost to the even start
+    if (span < 2) span = 2;
+    if (full || span >= b.VM) { full = true; span = b.VM; }
+    b.up = up; b.wp = span >> 1; b.full = full;
+    b.magic = b.wp > 1 ? (unsigned)(0x100000000ULL / (unsigned)b.wp) + 1u : 0u;
+    return b;
+}
+// byte offset, within a column block, of pair e of the window
+__device__ __forceinline__ unsigned w3_pair_offset(unsigned e, const W3Win &w, int VM) {
+    const unsigned c = w.wp == 1 ? e : __umulhi(e, w.magic);
+    const unsigned q = e - c * (unsigned)w.wp;
+    return (c * (unsigned)VM + (unsigned)w.row0) * 8u + q * 16u;
+}
 // Every fetch issues exactly SPB loads and every step runs the same straight-line code (no branch decides whether a
 // load is issued): the compiler can then count the loads in flight and wait for the oldest block only.  A slot past
-// the block's end re-reads the block's last pair, a block index past the last step re-reads the last block; what
+// the window's end re-reads the window's last pair, a block index past the last step re-reads the last block; what
 // they deliver is never used.
 template <int SPB>
-__device__ __forceinline__ void w3_fetch(v2d (&r)[SPB], const double *src, int n2, int lw, unsigned lane) {
+__device__ __forceinline__ void w3_fetch(v2d (&r)[SPB], const double *src, const W3Win &w, int VM, int lw, unsigned lane) {
     const unsigned l = opaque(lane);  // keeps the per-slot offsets from being precomputed and held in registers
-    const unsigned last = (unsigned)n2 - 1u;
+    const unsigned last = (unsigned)w.n2 - 1u;
 #pragma unroll
     for (int u = 0; u < SPB; ++u) {
         const unsigned e = 64u * (unsigned)(u * kLoaders + lw) + l;  // pair index: wave-uniform slot base + lane
-        r[u] = *(const v2d *)((const char *)src + (e < last ? e : last) * 16u);
+        r[u] = *(const v2d *)((const char *)src + w3_pair_offset(e < last ? e : last, w, VM));
     }
 }
 template <int SPB>
-__device__ __forceinline__ void w3_commit(const v2d (&r)[SPB], double *dst, int n2, int lw, unsigned lane) {
+__device__ __forceinline__ void w3_commit(const v2d (&r)[SPB], double *dst, const W3Win &w, int VM, int lw, unsigned lane) {
     const unsigned l = opaque(lane);
 #pragma unroll
     for (int u = 0; u < SPB; ++u) {
         const unsigned e = 64u * (unsigned)(u * kLoaders + lw) + l;
-        if ((int)e < n2) *(v2d *)((char *)dst + e * 16u) = r[u];
+        if ((int)e < w.n2) *(v2d *)((char *)dst + w3_pair_offset(e, w, VM)) = r[u];
     }
 }
 // The loader waves' side of the sweep: v steps, one lds_barrier() each, matching the compute waves' loop.
@@ -135,16 +187,16 @@ struct W3Loader {
     using Regs = v2d[NBR][SPB];
     const double *gW3;
     double *sW3;
-    int v, wcnt, n2, lw;
+    W3Band band;
+    int v, wcnt, VM, m, lw;
     unsigned ltid;
 
-    __device__ __forceinline__ const double *block_of(int step) const {
-        const int st = step < v ? step : v - 1;
-        return gW3 + (long long)(v - 1 - st) * wcnt;
-    }
+    __device__ __forceinline__ int blk_of(int step) const { return v - 1 - (step < v ? step : v - 1); }
+    __device__ __forceinline__ const double *block_of(int step) const { return gW3 + (long long)blk_of(step) * wcnt; }
+    __device__ __forceinline__ W3Win win_of(int step) const { return band.window(blk_of(step)); }
     template <int U>
     __device__ __forceinline__ void prefetch(Regs &reg) const {  // U = 1 .. NB: the block of step U, into set U % NB
-        if (NB > 0) w3_fetch<SPB>(reg[U % NBR], block_of(U), n2, lw, ltid);
+        if (NB > 0) w3_fetch<SPB>(reg[U % NBR], block_of(U), win_of(U), VM, lw, ltid);
     }
     // Step s0 + U: the block of the next step goes to the ring slot that step reads (past the last step this writes
     // the slot nobody reads any more), and its register set is refilled with the block NB steps further on.
@@ -154,8 +206,8 @@ struct W3Loader {
         constexpr int SET = (U + 1) % NBR;
         double *dst = sW3 + ((v - 2 - s) & 1) * wcnt;
         if (NB > 0) {
-            w3_commit<SPB>(reg[SET], dst, n2, lw, ltid);
-            w3_fetch<SPB>(reg[SET], block_of(s + 1 + NBR), n2, lw, ltid);
+            w3_commit<SPB>(reg[SET], dst, win_of(s + 1), VM, lw, ltid);
+            w3_fetch<SPB>(reg[SET], block_of(s + 1 + NBR), win_of(s + 1 + NBR), VM, lw, ltid);
         } else if (s + 1 < v) {
             const double *src = block_of(s + 1);
             for (int e = ltid + 64 * lw; e < wcnt; e += 64 * kLoaders) dst[e] = src[e];
@@ -176,21 +228,49 @@ struct W3Loader {
     }
 };
 template <int NB>
-__device__ __forceinline__ void w3_loader_sweep(const double *gW3, double *sW3, int v, int wcnt, int lw, unsigned ltid) {
+__device__ __forceinline__ void w3_loader_sweep(const double *gW3, double *sW3, const W3Band &band, int v, int m, int lw,
+                                                unsigned ltid) {
     W3Loader<NB> L;
-    L.gW3 = gW3; L.sW3 = sW3; L.v = v; L.wcnt = wcnt; L.n2 = wcnt >> 1; L.lw = lw; L.ltid = ltid;
+    L.gW3 = gW3; L.sW3 = sW3; L.band = band; L.v = v; L.m = m; L.VM = v * m; L.wcnt = v * m * m; L.lw = lw; L.ltid = ltid;
     L.run(std::make_integer_sequence<int, W3Loader<NB>::NBR>{});
 }
-__device__ __forceinline__ void w3_loader_run(const double *gW3, double *sW3, int v, int wcnt, int lw, int ltid, bool wide) {
+__device__ __forceinline__ void w3_loader_run(const double *gW3, double *sW3, const int *reach, int v, int m, int lw, int ltid,
+                                              bool wide) {
     lw = __builtin_amdgcn_readfirstlane(lw);  // wave-uniform by construction; tell the compiler
-    // slots of a block that one wave moves
-    const int spw = (((wcnt >> 1) + 63) / 64 + kLoaders - 1) / kLoaders;
-    if (!wide || spw > kPreTotal) w3_loader_sweep<0>(gW3, sW3, v, wcnt, lw, (unsigned)ltid);
-    else if (spw <= kPreTotal / 8) w3_loader_sweep<8>(gW3, sW3, v, wcnt, lw, (unsigned)ltid);
-    else if (spw <= kPreTotal / 5) w3_loader_sweep<5>(gW3, sW3, v, wcnt, lw, (unsigned)ltid);
-    else if (spw <= kPreTotal / 3) w3_loader_sweep<3>(gW3, sW3, v, wcnt, lw, (unsigned)ltid);
-    else if (spw <= kPreTotal / 2) w3_loader_sweep<2>(gW3, sW3, v, wcnt, lw, (unsigned)ltid);
-    else w3_loader_sweep<1>(gW3, sW3, v, wcnt, lw, (unsigned)ltid);
+    const W3Band band = w3_band_setup(wide ? reach : nullptr, v, m);
+    // slots of a window that one wave moves
+    const int spw = ((m * band.wp + 63) / 64 + kLoaders - 1) / kLoaders;
+    if (!wide || spw > kPreTotal) w3_loader_sweep<0>(gW3, sW3, band, v, m, lw, (unsigned)ltid);
+    else if (spw <= kPreTotal / 8) w3_loader_sweep<8>(gW3, sW3, band, v, m, lw, (unsigned)ltid);
+    else if (spw <= kPreTotal / 5) w3_loader_sweep<5>(gW3, sW3, band, v, m, lw, (unsigned)ltid);
+    else if (spw <= kPreTotal / 3) w3_loader_sweep<3>(gW3, sW3, band, v, m, lw, (unsigned)ltid);
+    else if (spw <= kPreTotal / 2) w3_loader_sweep<2>(gW3, sW3, band, v, m, lw, (unsigned)ltid);
+    else w3_loader_sweep<1>(gW3, sW3, band, v, m, lw, (unsigned)ltid);
+}
+
+// One workgroup per column block bb of W3 ((v m) x (v m), column-major): how far its non-zeros (NaNs included) reach
+// above and below row bb m, folded into reach[0] / reach[1] by atomic maximum (the caller sets both to INT_MIN first).
+__global__ __launch_bounds__(256) void w3_band_kernel(const double *__restrict__ W3, int v, int m, int *reach) {
+    __shared__ int slo, shi;
+    const int bb = blockIdx.x, VM = v * m;
+    if (threadIdx.x == 0) { slo = VM; shi = 0; }
+    __syncthreads();
+    int lo = VM, hi = 0;
+    const double *src = W3 + (long long)bb * VM * m;
+    for (int e = threadIdx.x; e < VM * m; e += 256) {
+        if (!(src[e] == 0.0)) {
+            const int row = e % VM;
+            lo = row < lo ? row : lo;
+            hi = row + 1 > hi ? row + 1 : hi;
+        }
+    }
+    atomicMin(&slo, lo);
+    atomicMax(&shi, hi);
+    __syncthreads();
+    if (threadIdx.x == 0 && shi > slo) {
+        atomicMax(&reach[0], bb * m - slo);
+        atomicMax(&reach[1], shi - bb * m);
+    }
 }
 
 // HM, HR, ITEMS > 0: the H sweep is specialised for m = HM, r = HR with up to ITEMS (block row, column) pairs per
@@ -254,44 +334,90 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     }
     const bool one_task = (nT <= kCompute) && (n <= kCoef);
     if (one_task) {
-        // decode this thread's task once; its coefficients stay in registers for all f steps
+        // Stride: the recurrences are a serial chain of f steps, one LDS round trip and one barrier each.  Where the
+        // threads allow it a step advances the states by A^st (st = 4 or 2) and produces the st Markov blocks, Phi
+        // blocks and s vectors in between from the same state: G_(k+j) = (C A^j) W_k, Phi block k+j = P_k A^(j+1),
+        // s_(k+j) = P_k (A^(j+1) x0) - ref_(k+j).  Still one dot product per thread and step, f / st steps.
+        int st = 1;
+        if (f % 4 == 0 && 4 * (nG + nP + nS) + nW <= kCompute) st = 4;
+        else if (f % 2 == 0 && 2 * (nG + nP + nS) + nW <= kCompute) st = 2;
+        double *sPow = lds + L.Pow, *sCA = sPow + 3 * n * n, *sAjx = sCA + 3 * r * n;
+        auto Apow = [&](int j) -> const double * { return j == 1 ? sA : sPow + (j - 2) * n * n; };   // A^j, j = 1..4
+        auto CApow = [&](int j) -> const double * { return j == 0 ? sC : sCA + (j - 1) * r * n; };  // C A^j, j = 0..3
+        auto Ajx = [&](int j) -> const double * { return j == 1 ? sAx : sAjx + (j - 1) * n; };      // A^j x0, j = 1..4
+        if (st > 1) {
+            auto matmul = [&](double *dst, const double *X, const double *Y, int rows) {  // dst (rows x n) = X (rows x n) Y (n x n)
+                for (int e = tid; e < rows * n; e += kWgBlock) {
+                    const int i = e % rows, j2 = e / rows;
+                    double acc = 0.0;
+                    for (int q = 0; q < n; ++q) acc += X[q * rows + i] * Y[j2 * n + q];
+                    dst[e] = acc;
+                }
+            };
+            matmul(sPow, sA, sA, n);
+            lds_barrier();
+            if (st > 2) {
+                matmul(sPow + n * n, sPow, sA, n);
+                matmul(sPow + 2 * n * n, sPow, sPow, n);
+                lds_barrier();
+            }
+            for (int j = 1; j < st; ++j) matmul(sCA + (j - 1) * r * n, sC, Apow(j), r);
+            if (p.fvec) {
+                for (int e = tid; e < (st - 1) * n; e += kWgBlock) {  // A^j x0 = A^j times x0, j = 2..st
+                    const int j = 2 + e / n, i = e % n;
+                    const double *X = Apow(j);
+                    double acc = 0.0;
+                    for (int q = 0; q < n; ++q) acc += X[q * n + i] * sx0[q];
+                    sAjx[(j - 1) * n + i] = acc;
+                }
+            }
+            lds_barrier();
+        }
+        // decode this thread's task once; its coefficients stay in registers for all steps
+        const int tG = st * nG, tP = st * nP, tS = st * nS, nTs = tG + nW + tP + tS;
         int kind = -1, op_off = 0, op_stride = 1, out_off = 0;
+        bool wr_state = true;
         long long phi_off = 0;
         double coef[kCoef];
 #pragma unroll
         for (int j = 0; j < kCoef; ++j) coef[j] = 0.0;
-        if (!loader && tid < nT) {
-            if (tid < nG) {
-                const int a = tid % r, c = tid / r;
-                kind = 0; op_off = c * n; op_stride = 1; out_off = c * FR + a;
+        if (!loader && tid < nTs) {
+            if (tid < tG) {
+                const int jj = tid / nG, u = tid - jj * nG, a = u % r, c = u / r;
+                const double *X = CApow(jj);
+                kind = 0; op_off = c * n; op_stride = 1; out_off = c * FR + jj * r + a;
 #pragma unroll
-                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = sC[j * r + a];
-            } else if (tid < nG + nW) {
-                const int u = tid - nG, i = u % n, c = u / n;
+                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = X[j * r + a];
+            } else if (tid < tG + nW) {
+                const int u = tid - tG, i = u % n, c = u / n;
+                const double *X = Apow(st);
                 kind = 1; op_off = c * n; op_stride = 1; out_off = u;
 #pragma unroll
-                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = sA[j * n + i];
-            } else if (tid < nG + nW + nP) {
-                const int u = tid - nG - nW, a = u % r, j2 = u / r;
-                kind = 2; op_off = a; op_stride = r; out_off = u; phi_off = (long long)j2 * FR + a;
+                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = X[j * n + i];
+            } else if (tid < tG + nW + tP) {
+                const int t2 = tid - tG - nW, jj = t2 / nP, u = t2 - jj * nP, a = u % r, j2 = u / r;
+                const double *X = Apow(jj + 1);
+                kind = 2; op_off = a; op_stride = r; out_off = u; phi_off = (long long)j2 * FR + jj * r + a;
+                wr_state = (jj == st - 1);
 #pragma unroll
-                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = sA[j2 * n + j];
+                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = X[j2 * n + j];
             } else {
-                const int a = tid - nG - nW - nP;
-                kind = 3; op_off = a; op_stride = r; out_off = a;
+                const int t2 = tid - tG - nW - tP, jj = t2 / r, a = t2 - jj * r;
+                const double *X = Ajx(jj + 1);
+                kind = 3; op_off = a; op_stride = r; out_off = jj * r + a;
 #pragma unroll
-                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = sAx[j];
+                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = X[j];
             }
         }
         // The dot product is as long as the smallest of 8, 12, 16 that holds n (shorter serial chain, fewer LDS reads),
         // and runs as two partial sums.
         auto recur = [&](auto width) {
             constexpr int KC = decltype(width)::value;
-            for (int k = 0; k < f; ++k) {
-                const double *Wc = sW + (k & 1) * nW;
-                double *Wn = sW + ((k + 1) & 1) * nW;
-                const double *Pc = sP + (k & 1) * nP;
-                double *Pn = sP + ((k + 1) & 1) * nP;
+            for (int k = 0, it = 0; k < f; k += st, ++it) {
+                const double *Wc = sW + (it & 1) * nW;
+                double *Wn = sW + ((it + 1) & 1) * nW;
+                const double *Pc = sP + (it & 1) * nP;
+                double *Pn = sP + ((it + 1) & 1) * nP;
                 if (kind >= 0) {
                     const double *op = (kind >= 2 ? Pc : Wc) + op_off;
                     double s0 = 0.0, s1 = 0.0;
@@ -307,7 +433,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                     } else if (kind == 1) {
                         Wn[out_off] = s;
                     } else if (kind == 2) {
-                        Pn[out_off] = s;
+                        if (wr_state) Pn[out_off] = s;
                         if (gPhi) gPhi[phi_off + k * r] = s;
                     } else {
                         sSr[k * r + out_off] = s - sSr[k * r + out_off];
@@ -449,10 +575,10 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         // W3 pipeline of the loader wave: block v-1 goes straight to its slot, block v-2 is fetched ahead
         const int wcnt = VM * m;  // doubles in one column block of W3
         const bool wide = ((wcnt & 1) == 0) && (((uintptr_t)p.W3 & 15) == 0);
-        if (loader) {
+        if (loader) {  // block v-1 whole; the other slot starts as zeros (the loader then moves windows only)
             const double *src = p.W3 + (long long)(v - 1) * wcnt;
-            double *dst = sW3 + ((v - 1) & 1) * wcnt;
-            for (int e = tid - kCompute; e < wcnt; e += 64 * kLoaders) dst[e] = src[e];
+            double *dst = sW3 + ((v - 1) & 1) * wcnt, *oth = sW3 + (v & 1) * wcnt;
+            for (int e = tid - kCompute; e < wcnt; e += 64 * kLoaders) { dst[e] = src[e]; oth[e] = 0.0; }
         }
         const int bsz = m * m, tsz = v * bsz;
         const bool held = HM > 0 ? HELD : nl > 1;
@@ -489,7 +615,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             // Two loops with the same number of barriers: the loader wave's and the compute waves'.  Keeping them
             // apart keeps the loader's fetch registers and the compute waves' G blocks out of each other's live ranges.
             if (loader) {
-                w3_loader_run(p.W3, sW3, v, wcnt, lw, ltid, wide);
+                w3_loader_run(p.W3, sW3, (const int *)p.w3win, v, m, lw, ltid, wide);
             } else {
                 STAMP(6);
                 for (int bb = v - 1; bb >= 0; --bb) {
@@ -575,7 +701,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             // Two loops with the same number of barriers: the loader wave's and the compute waves'.  Keeping them
             // apart keeps the loader's fetch registers and the compute waves' G blocks out of each other's live ranges.
             if (loader) {
-                w3_loader_run(p.W3, sW3, v, wcnt, lw, ltid, wide);
+                w3_loader_run(p.W3, sW3, (const int *)p.w3win, v, m, lw, ltid, wide);
             } else {
                 for (int bb = v - 1; bb >= 0; --bb) {
                     double *cur = sHp + (bb & 1) * VM * m;
@@ -636,15 +762,27 @@ int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s) {
     if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
     if ((long long)a.f * a.r * a.v * a.m > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     if (a.batch > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    // reach of W3's non-zeros around the block diagonal, for the sweep's loader waves (only where they move 16-byte pairs)
+    QpArgs b = a;
+    const long long wcnt = (long long)a.v * a.m * a.m;
+    if (a.H && a.W3 && a.w3win && (wcnt & 1) == 0 && ((uintptr_t)a.W3 & 15) == 0 && a.w3win_bytes >= 2 * sizeof(int)) {
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.w3win, INT_MIN, 2, s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(w3_band_kernel, dim3((unsigned)a.v), dim3(256), 0, s, a.W3, a.v, a.m, (int *)a.w3win);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    } else {
+        b.w3win = nullptr;
+    }
     const long long items = ((long long)a.v * a.m + kCompute - 1) / kCompute;
     // 16-byte stores of the specialised sweep: the leading dimension v m is even whenever m is; the base must be too
     const bool even_rows = (a.m % 2 != 0) || (((uintptr_t)a.H & 15) == 0);
 #define FAST(M_, R_, I_) \
     if (a.m == M_ && a.r == R_ && items <= I_ && even_rows)                                        \
-        return a.f > a.v ? launch_wg_k<M_, R_, I_, true>(a, lds_bytes, s) : launch_wg_k<M_, R_, I_, false>(a, lds_bytes, s);
+        return a.f > a.v ? launch_wg_k<M_, R_, I_, true>(b, lds_bytes, s) : launch_wg_k<M_, R_, I_, false>(b, lds_bytes, s);
     FAST(4, 12, 1) FAST(2, 2, 4) FAST(1, 1, 4) FAST(4, 4, 2) FAST(3, 3, 2) FAST(2, 4, 2)
 #undef FAST
-    return launch_wg_k<0, 0, 1, false>(a, lds_bytes, s);
+    return launch_wg_k<0, 0, 1, false>(b, lds_bytes, s);
 }
 
 }  // namespace mpcx

@@ -63,6 +63,48 @@ def test_workgroup_kernel_shapes(ctx, n, m, r, f, v):
         assert_close(got[k], want[k], f"wg n{n} m{m} r{r} f{f} v{v} {k}")
 
 
+@pytest.mark.parametrize("n,m,r,f,v", [(8, 2, 2, 40, 40), (8, 2, 2, 30, 7), (12, 4, 12, 10, 10), (9, 1, 1, 300, 300),
+                                       (7, 3, 3, 9, 5), (8, 4, 4, 11, 11), (9, 2, 4, 8, 8), (20, 2, 2, 6, 6)])
+@pytest.mark.parametrize("pattern", ["tridiagonal", "zero", "spikes", "lower", "one_column", "nan"])
+def test_workgroup_kernel_sparse_input_weight(ctx, n, m, r, f, v, pattern):
+    """W3 with exact zeros: the workgroup kernels fetch, per column block, only the rows that hold non-zeros (of that
+    block and of the block two to its right), so every zero pattern must give the same H as the dense path.
+    "tridiagonal" is what Controller::new builds (controller.rs:149-177)."""
+    rng = np.random.default_rng(n * 11 + m * 5 + r * 3 + f + v + len(pattern))
+    batch, vm = 5, v * m
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    dense = rng.standard_normal((vm, vm))
+    if pattern == "tridiagonal":
+        w3, _ = synth.block_weights(m, r, v, 0.3, 0.7, 1.0)
+    elif pattern == "zero":
+        w3 = np.zeros((vm, vm))
+    elif pattern == "spikes":  # a few isolated entries anywhere, corners included
+        w3 = np.zeros((vm, vm))
+        w3[0, vm - 1] = 2.0
+        w3[vm - 1, 0] = -3.0
+        for _ in range(4):
+            w3[rng.integers(vm), rng.integers(vm)] = rng.standard_normal()
+    elif pattern == "lower":
+        w3 = np.tril(dense)
+    elif pattern == "one_column":
+        w3 = np.zeros((vm, vm))
+        w3[:, vm // 2] = dense[:, 0]
+    else:  # a NaN counts as a non-zero and must reach H
+        w3 = np.zeros((vm, vm))
+        w3[vm // 3, vm // 2] = np.nan
+    data = dict(A=A, B=B, C=C, W3=w3, Q=rng.standard_normal((r, r)), x0=rng.standard_normal((batch, n)),
+                ref=rng.standard_normal((batch, f * r)), f=f, v=v)
+    got = _run(ctx, data, 1, want=("H",))["H"]
+    base = _run(ctx, dict(data, W3=np.zeros((vm, vm))), 1, want=("H",))["H"]  # Gamma^T Qbar Gamma alone
+    want = base + w3[None]
+    if pattern == "nan":
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        got, want = np.nan_to_num(got), np.nan_to_num(want)
+    assert np.array_equal(got, want), f"{pattern}: H differs from (H with W3 = 0) + W3 in {np.count_nonzero(got != want)} entries"
+    if pattern != "nan":
+        assert_close(got, oracle_qp(orc, data, want=("H",))["H"], f"wg sparse W3 {pattern} n{n} m{m} r{r} f{f} v{v} H")
+
+
 def test_quadrotor_and_long_horizon_workloads(ctx):
     for name, batch in (("quadrotor", 6), ("long", 2)):
         data = synth.make_batch(name, batch)
