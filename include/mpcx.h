@@ -41,7 +41,7 @@ extern "C" {
 #define MPCX_OK 0
 #define MPCX_ERR_NULL (-1)        /* a required pointer is NULL */
 #define MPCX_ERR_DIMS (-2)        /* a dimension is out of range (n, m, r, f >= 1; 1 <= v <= f; batch, T >= 0) */
-#define MPCX_ERR_LAYOUT (-3)      /* interleave value not supported for these dimensions */
+#define MPCX_ERR_LAYOUT (-3)      /* interleave is not 0, 1 or a multiple of 64 */
 #define MPCX_ERR_UNSUPPORTED (-4) /* combination of dimensions / modes exceeds what the kernels hold on chip */
 #define MPCX_ERR_NO_DEVICE (-5)   /* no usable HIP device */
 #define MPCX_ERR_SINGULAR (-6)    /* reported per instance through `info`, see mpcx_qp_gain_* */
@@ -105,6 +105,13 @@ const char *mpcx_last_error(const mpcx_ctx *ctx);
  * Inputs per instance: A, B, C, x0 (n), ref (f r).  Shared: W3 (v m x v m dense), W4 (r x r block or dense
  * (f r) x (f r), per dims->weights_mode).  Any output pointer may be NULL: that output is neither computed
  * for its own sake nor stored.  x0 / ref may be NULL when fvec is NULL; W3 / W4 when H and fvec are NULL.
+ * Every layout is accepted for every shape.  Plants of up to 6 states and 2 inputs / outputs are native in the
+ * interleaved layouts (one lane per instance); larger ones, MPCX_WEIGHTS_DENSE and MPCX_HESSIAN_CONTRACT are native
+ * in interleave = 1, and an interleaved batch then goes through an instance-major copy in device scratch that the
+ * context owns (at most 2 GiB at a time; every output is moved three times).  Exact zeros of W3 are skipped: the
+ * band structure of W3 is measured on the device by each call (W3 as Controller::new builds it is block tridiagonal,
+ * controller.rs:149-177).  The context's scratch is shared by all its calls: do not run two calls of one context
+ * concurrently on different streams.
  */
 int mpcx_qp_build_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, const double *B, const double *C,
                       const double *W3, const double *W4, const double *x0, const double *ref, double *Phi,

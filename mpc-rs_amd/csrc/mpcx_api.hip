@@ -2,6 +2,7 @@
 // There is no CPU implementation behind these entry points.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -18,6 +19,8 @@ struct mpcx_ctx {
     void *aux;           // I - Ac dt of the general discretisation
     size_t aux_bytes;
     void *stat_scratch;  // partial records of the stats reduction + one result record
+    void *relay;         // instance-major copy of a chunk of the batch (interleaved data on the workgroup kernels)
+    size_t relay_bytes;
     void *w3win;         // band structure of W3, measured on the device by every build call of the workgroup kernels
     size_t w3win_bytes;
     char err[512];
@@ -151,6 +154,8 @@ int mpcx_create(mpcx_ctx **out, int device_id) {
     ctx->stat_scratch = nullptr;
     ctx->w3win = nullptr;
     ctx->w3win_bytes = 0;
+    ctx->relay = nullptr;
+    ctx->relay_bytes = 0;
     ctx->err[0] = 0;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -176,11 +181,117 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->stat_scratch) (void)hipFree(ctx->stat_scratch);
     if (ctx->w3win) (void)hipFree(ctx->w3win);
+    if (ctx->relay) (void)hipFree(ctx->relay);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 const char *mpcx_last_error(const mpcx_ctx *ctx) { return ctx ? ctx->err : "context is NULL"; }
+
+// Kernel-family dispatch of one build on prepared arguments.  The dense-weight kernel, the matrix-core contraction and
+// the workgroup kernels take instance-major data (a.W == 1); the caller re-lays interleaved batches out for them.
+static int qp_build_core(mpcx_ctx *ctx, const mpcx_dims *d, QpArgs a, hipStream_t s) {
+    int rc;
+    if (d->weights_mode == MPCX_WEIGHTS_DENSE && (a.H || a.fvec)) {
+        // dense W4: H and fvec from the column-by-column kernel, Phi and Gamma from the build kernels
+        rc = launch_qp_dense(a, s);
+        if (rc == MPCX_ERR_UNSUPPORTED)
+            return fail(ctx, rc, "weights_mode = DENSE: n=%d m=%d r=%d f=%d v=%d exceeds the kernel's on-chip working set",
+                        d->n, d->m, d->r, d->f, d->v);
+        if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "qp_dense launch");
+        a.H = nullptr;
+        a.fvec = nullptr;
+        if (!a.Phi && !a.Gamma) return MPCX_OK;
+    }
+    if (a.H && d->hessian_algo == MPCX_HESSIAN_CONTRACT) {
+        // dense contraction on the matrix cores: H from its own kernel, everything else from the build kernels
+        rc = launch_hessian_mfma(a, s);
+        if (rc == MPCX_ERR_UNSUPPORTED)
+            return fail(ctx, rc, "hessian_algo = CONTRACT: n=%d m=%d r=%d f=%d v=%d weights_mode=%d exceeds the kernel's on-chip working set",
+                        d->n, d->m, d->r, d->f, d->v, d->weights_mode);
+        if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "hessian_mfma launch");
+        a.H = nullptr;
+        if (!a.Phi && !a.Gamma && !a.fvec) return MPCX_OK;
+    }
+    rc = launch_qp_lane(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED) rc = launch_qp_wg(a, d->hessian_algo, s);
+    if (rc == MPCX_ERR_LAYOUT)
+        return fail(ctx, rc, "n=%d m=%d r=%d needs the workgroup kernels, which take instance-major data (interleave = 1)",
+                    d->n, d->m, d->r);
+    if (rc == MPCX_ERR_UNSUPPORTED)
+        return fail(ctx, rc, "n=%d m=%d r=%d f=%d v=%d weights_mode=%d does not fit the on-chip working set of any kernel",
+                    d->n, d->m, d->r, d->f, d->v, d->weights_mode);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "qp_build launch");
+    return MPCX_OK;
+}
+
+// Interleaved batch on kernels that take instance-major data: the batch goes through an instance-major copy in chunks
+// of at most kRelayCap bytes (inputs re-laid out into the context's scratch, built there, outputs re-laid out into the
+// caller's arrays).  A compatibility path: it moves every output three times.
+constexpr size_t kRelayCap = (size_t)2 << 30;
+static int qp_build_relayed(mpcx_ctx *ctx, const mpcx_dims *d, const QpArgs &a, hipStream_t s) {
+    const long long n = a.n, m = a.m, r = a.r, FR = (long long)a.f * a.r, VM = (long long)a.v * a.m;
+    const double *in[5] = {a.A, a.B, a.C, a.fvec ? a.x0 : nullptr, a.fvec ? a.ref : nullptr};
+    const long long in_e[5] = {n * n, n * m, r * n, n, FR};
+    double *out[4] = {a.Phi, a.Gamma, a.H, a.fvec};
+    const long long out_e[4] = {FR * n, FR * VM, VM * VM, VM};
+    long long per = 0;
+    for (int i = 0; i < 5; ++i) per += in[i] ? in_e[i] : 0;
+    for (int i = 0; i < 4; ++i) per += out[i] ? out_e[i] : 0;
+    size_t cap = kRelayCap;
+    if (const char *env = getenv("MPCX_RELAY_CAP_BYTES")) {  // test knob: a small cap exercises the chunking
+        const long long v = atoll(env);
+        if (v > 0) cap = (size_t)v;
+    }
+    long long cnt = (long long)(cap / ((size_t)per * sizeof(double)));
+    if (cnt < 1) cnt = 1;
+    if (cnt >= 64) cnt &= ~63LL;
+    if (cnt > a.batch) cnt = a.batch;
+    const size_t want = (size_t)cnt * (size_t)per * sizeof(double);
+    if (want > ctx->relay_bytes) {
+        if (ctx->relay) {
+            HIP_TRY(ctx, hipFree(ctx->relay));
+            ctx->relay = nullptr;
+            ctx->relay_bytes = 0;
+        }
+        HIP_TRY(ctx, hipMalloc(&ctx->relay, want));
+        ctx->relay_bytes = want;
+    }
+    for (long long c0 = 0; c0 < a.batch; c0 += cnt) {
+        const long long cc = a.batch - c0 < cnt ? a.batch - c0 : cnt;
+        double *w = (double *)ctx->relay;
+        const double *win[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        double *wout[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < 5; ++i) {
+            if (!in[i]) continue;
+            const int rc = launch_relayout(cc, in_e[i], a.W, in[i], 1, w, s, c0, 0);
+            if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "interleaved batch: an input array is too large to re-lay out");
+            if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "relayout launch");
+            win[i] = w;
+            w += cc * in_e[i];
+        }
+        for (int i = 0; i < 4; ++i) {
+            if (!out[i]) continue;
+            wout[i] = w;
+            w += cc * out_e[i];
+        }
+        QpArgs c = a;
+        c.A = win[0]; c.B = win[1]; c.C = win[2]; c.x0 = win[3]; c.ref = win[4];
+        c.Phi = wout[0]; c.Gamma = wout[1]; c.H = wout[2]; c.fvec = wout[3];
+        c.batch = cc; c.W = 1;
+        int rc = qp_build_core(ctx, d, c, s);
+        if (rc != MPCX_OK) return rc;
+        for (int i = 0; i < 4; ++i) {
+            if (!out[i]) continue;
+            rc = launch_relayout(cc, out_e[i], 1, wout[i], a.W, out[i], s, 0, c0);
+            if (rc == MPCX_ERR_UNSUPPORTED)
+                return fail(ctx, rc, "interleaved batch: %lld elements per instance are too many to re-lay out (use interleave = 1)",
+                            out_e[i]);
+            if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "relayout launch");
+        }
+    }
+    return MPCX_OK;
+}
 
 int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,
                           const double *W3, const double *W4, const double *x0, const double *ref, double *Phi,
@@ -192,6 +303,9 @@ int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, co
         return fail(ctx, MPCX_ERR_DIMS, "need f >= 1 and 1 <= v <= f (got f=%d, v=%d)", d->f, d->v);
     if (d->weights_mode != MPCX_WEIGHTS_BLOCK && d->weights_mode != MPCX_WEIGHTS_DENSE)
         return fail(ctx, MPCX_ERR_DIMS, "unknown weights_mode %d", d->weights_mode);
+    if (d->hessian_algo != MPCX_HESSIAN_AUTO && d->hessian_algo != MPCX_HESSIAN_CONTRACT &&
+        d->hessian_algo != MPCX_HESSIAN_STRUCTURED)
+        return fail(ctx, MPCX_ERR_DIMS, "unknown hessian_algo %d", d->hessian_algo);
     if (d->batch == 0) return MPCX_OK;
     if (!A || !B || !C) return fail(ctx, MPCX_ERR_NULL, "A, B and C are required");
     if ((H || fvec) && !W4) return fail(ctx, MPCX_ERR_NULL, "W4 is required when H or fvec is requested");
@@ -218,43 +332,10 @@ int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, co
         a.w3win = ctx->w3win;
         a.w3win_bytes = ctx->w3win_bytes;
     }
-    if (d->hessian_algo != MPCX_HESSIAN_AUTO && d->hessian_algo != MPCX_HESSIAN_CONTRACT &&
-        d->hessian_algo != MPCX_HESSIAN_STRUCTURED)
-        return fail(ctx, MPCX_ERR_DIMS, "unknown hessian_algo %d", d->hessian_algo);
-    if (d->weights_mode == MPCX_WEIGHTS_DENSE && (H || fvec)) {
-        // dense W4: H and fvec from the column-by-column kernel, Phi and Gamma from the build kernels
-        if (W != 1) return fail(ctx, MPCX_ERR_LAYOUT, "weights_mode = DENSE takes instance-major data (interleave = 1)");
-        rc = launch_qp_dense(a, s);
-        if (rc == MPCX_ERR_UNSUPPORTED)
-            return fail(ctx, rc, "weights_mode = DENSE: n=%d m=%d r=%d f=%d v=%d exceeds the kernel's on-chip working set",
-                        d->n, d->m, d->r, d->f, d->v);
-        if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "qp_dense launch");
-        a.H = nullptr;
-        a.fvec = nullptr;
-        if (!Phi && !Gamma) return MPCX_OK;
-    }
-    if (a.H && d->hessian_algo == MPCX_HESSIAN_CONTRACT) {
-        // dense contraction on the matrix cores: H from its own kernel, everything else from the build kernels
-        if (W != 1)
-            return fail(ctx, MPCX_ERR_LAYOUT, "hessian_algo = CONTRACT takes instance-major data (interleave = 1)");
-        rc = launch_hessian_mfma(a, s);
-        if (rc == MPCX_ERR_UNSUPPORTED)
-            return fail(ctx, rc, "hessian_algo = CONTRACT: n=%d m=%d r=%d f=%d v=%d weights_mode=%d exceeds the kernel's on-chip working set",
-                        d->n, d->m, d->r, d->f, d->v, d->weights_mode);
-        if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "hessian_mfma launch");
-        a.H = nullptr;
-        if (!Phi && !Gamma && !fvec) return MPCX_OK;
-    }
-    rc = launch_qp_lane(a, s);
-    if (rc == MPCX_ERR_UNSUPPORTED) rc = launch_qp_wg(a, d->hessian_algo, s);
-    if (rc == MPCX_ERR_LAYOUT)
-        return fail(ctx, rc, "n=%d m=%d r=%d needs the workgroup kernels, which take instance-major data (interleave = 1)",
-                    d->n, d->m, d->r);
-    if (rc == MPCX_ERR_UNSUPPORTED)
-        return fail(ctx, rc, "n=%d m=%d r=%d f=%d v=%d weights_mode=%d does not fit the on-chip working set of any kernel",
-                    d->n, d->m, d->r, d->f, d->v, d->weights_mode);
-    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "qp_build launch");
-    return MPCX_OK;
+    // only the one-lane-per-instance kernels read and write interleaved batches directly
+    const bool lane_all = qp_lane_takes(a) && !(H && d->hessian_algo == MPCX_HESSIAN_CONTRACT);
+    if (W != 1 && !lane_all) return qp_build_relayed(ctx, d, a, s);
+    return qp_build_core(ctx, d, a, s);
 }
 
 int mpcx_qp_build_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, const double *B, const double *C,

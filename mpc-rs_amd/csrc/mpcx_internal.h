@@ -72,8 +72,13 @@ int launch_rollout_group(const RolloutArgs &a, hipStream_t s);
 int launch_stats(const double *buf, long long count, mpcx_stats *out_dev, void *scratch, size_t scratch_bytes,
                  hipStream_t s);
 size_t stats_scratch_bytes();
+// `batch` instances, starting at instance src_first of the source array and written from instance dst_first of the
+// destination array on (each array in its own interleave width)
 int launch_relayout(long long batch, long long E, long long Wsrc, const double *src, long long Wdst, double *dst,
-                    hipStream_t s);
+                    hipStream_t s, long long src_first = 0, long long dst_first = 0);
+// True when the one-lane-per-instance build kernels take this problem (any batch layout); everything else runs on the
+// one-workgroup-per-instance kernels, which take instance-major data.
+bool qp_lane_takes(const QpArgs &a);
 
 // Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also waits for every outstanding global store
 // of the wave (s_waitcnt vmcnt(0)), which in a loop that stores to HBM each step serialises the loop on the store

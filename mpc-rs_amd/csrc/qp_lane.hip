@@ -432,9 +432,16 @@ bool qp_lane_supports(int n, int m, int r) {
     return false;
 }
 
+bool qp_lane_takes(const QpArgs &a) {
+    if (a.weights_mode != MPCX_WEIGHTS_BLOCK && (a.H || a.fvec)) return false;
+    if (!qp_lane_supports(a.n, a.m, a.r)) return false;
+    if ((a.batch + kLaneBlock - 1) / kLaneBlock > 0x7fffffffLL) return false;
+    const size_t zh = (size_t)a.f * a.r > (size_t)a.v * a.m * a.m ? (size_t)a.f * a.r : (size_t)a.v * a.m * a.m;
+    return ((size_t)a.f * a.r * a.m + zh) * kLaneBlock * sizeof(double) <= 160 * 1024;  // as launch_one sizes its LDS
+}
+
 int launch_qp_lane(const QpArgs &a, hipStream_t s) {
-    if (a.weights_mode != MPCX_WEIGHTS_BLOCK && (a.H || a.fvec)) return MPCX_ERR_UNSUPPORTED;
-    if (!qp_lane_supports(a.n, a.m, a.r)) return MPCX_ERR_UNSUPPORTED;
+    if (!qp_lane_takes(a)) return MPCX_ERR_UNSUPPORTED;
 #define CASE(N_, M_, R_) \
     if (a.n == N_ && a.m == M_ && a.r == R_) return launch_one<N_, M_, R_>(a, s);
     CASE(1, 1, 1) CASE(2, 1, 1) CASE(3, 1, 1) CASE(4, 1, 1) CASE(5, 1, 1) CASE(6, 1, 1)

@@ -78,8 +78,9 @@ constexpr int kTile = 64;
 
 // dst and src hold the same (batch x E) values under two interleave widths.  A 64 x 64 (instance x element)
 // tile goes through LDS so that both the read and the write side run along their own contiguous direction.
+// Instance b of the call is instance sb0 + b of the source array and db0 + b of the destination array.
 __global__ __launch_bounds__(256) void relayout_kernel(long long batch, long long E, long long Ws, const double *src,
-                                                       long long Wd, double *dst) {
+                                                       long long sb0, long long Wd, double *dst, long long db0) {
     __shared__ double tile[kTile][kTile + 1];  // [instance][element]
     const long long b0 = (long long)blockIdx.x * kTile, e0 = (long long)blockIdx.y * kTile;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
@@ -87,13 +88,13 @@ __global__ __launch_bounds__(256) void relayout_kernel(long long batch, long lon
     for (int k = ty; k < kTile; k += 4) {
         const long long b = src_elem_fast ? b0 + k : b0 + tx;
         const long long e = src_elem_fast ? e0 + tx : e0 + k;
-        if (b < batch && e < E) tile[b - b0][e - e0] = src[elem_index(b, e, E, Ws)];
+        if (b < batch && e < E) tile[b - b0][e - e0] = src[elem_index(sb0 + b, e, E, Ws)];
     }
     __syncthreads();
     for (int k = ty; k < kTile; k += 4) {
         const long long b = dst_elem_fast ? b0 + k : b0 + tx;
         const long long e = dst_elem_fast ? e0 + tx : e0 + k;
-        if (b < batch && e < E) dst[elem_index(b, e, E, Wd)] = tile[b - b0][e - e0];
+        if (b < batch && e < E) dst[elem_index(db0 + b, e, E, Wd)] = tile[b - b0][e - e0];
     }
 }
 
@@ -113,12 +114,12 @@ int launch_stats(const double *buf, long long count, mpcx_stats *out_dev, void *
 }
 
 int launch_relayout(long long batch, long long E, long long Wsrc, const double *src, long long Wdst, double *dst,
-                    hipStream_t s) {
+                    hipStream_t s, long long src_first, long long dst_first) {
     if (batch == 0 || E == 0) return 0;
     const long long gx = (batch + kTile - 1) / kTile, gy = (E + kTile - 1) / kTile;
     if (gx > 0x7fffffffLL || gy > 65535) return MPCX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, batch, E, Wsrc, src, Wdst,
-                       dst);
+    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, s, batch, E, Wsrc, src, src_first,
+                       Wdst, dst, dst_first);
     return (int)hipGetLastError();
 }
 

@@ -4,6 +4,8 @@ Tolerance: relative Frobenius error <= 1e-10 per output, over the batch and for 
 (tests/helpers.py RTOL).  The GPU evaluates the same quantities with a different association (Markov recurrence
 instead of re-multiplied powers, running sums along block diagonals of H), so equality is not bitwise.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -149,10 +151,6 @@ def test_argument_errors(ctx):
     with pytest.raises(ffi.MpcxError) as e:
         _run(ctx, data, 48)  # not 0, 1 or a multiple of 64
     assert e.value.code == ffi.ERR_LAYOUT
-    big = synth.make_batch("quadrotor", 2)
-    with pytest.raises(ffi.MpcxError) as e:
-        _run(ctx, big, 0)  # workgroup kernels take instance-major data only
-    assert e.value.code == ffi.ERR_LAYOUT
 
 
 @pytest.mark.parametrize("n,m,r,f,v", [(12, 4, 12, 10, 10), (12, 4, 12, 9, 4), (8, 2, 2, 40, 40), (8, 2, 2, 30, 7),
@@ -175,11 +173,45 @@ def test_hessian_contraction_on_matrix_cores(ctx, n, m, r, f, v):
     assert_close(structured["H"], got["H"], "structured vs contraction")
 
 
-def test_hessian_contraction_needs_instance_major(ctx):
-    data = synth.make_batch("two_mass", 64)
-    with pytest.raises(ffi.MpcxError) as e:
-        _run(ctx, data, 0, hessian_algo=ffi.HESSIAN_CONTRACT)
-    assert e.value.code == ffi.ERR_LAYOUT
+@pytest.mark.parametrize("interleave", [0, 64, 128])
+@pytest.mark.parametrize("batch", [1, 70, 200])
+def test_interleaved_batches_on_the_instance_major_kernels(ctx, interleave, batch):
+    """The workgroup kernels, the matrix-core contraction and the dense-weight kernel take instance-major data; an
+    interleaved batch goes through an instance-major copy inside the library and must give the same bits as the
+    same call with interleave = 1 (ragged last tile, batch of one, output subsets included)."""
+    rng = np.random.default_rng(31 * batch + interleave)
+    for (n, m, r, f, v) in ((8, 2, 2, 12, 12), (12, 4, 12, 5, 3), (4, 1, 1, 170, 170)):  # the last: a lane shape too long for LDS
+        A, B, C = random_stable_plants(rng, batch, n, m, r)
+        data = dict(A=A, B=B, C=C, W3=rng.standard_normal((v * m, v * m)), Q=rng.standard_normal((r, r)),
+                    x0=rng.standard_normal((batch, n)), ref=rng.standard_normal((batch, f * r)), f=f, v=v)
+        base = _run(ctx, data, 1)
+        got = _run(ctx, data, interleave)
+        for k in ("Phi", "Gamma", "H", "fvec"):
+            assert np.array_equal(got[k], base[k]), f"n{n} m{m} r{r} W={interleave} batch {batch}: {k} differs from interleave = 1"
+        part = _run(ctx, data, interleave, want=("Gamma", "fvec"))
+        assert np.array_equal(part["Gamma"], base["Gamma"]) and np.array_equal(part["fvec"], base["fvec"])
+        if batch == 200:  # a scratch cap of 3.5 instances' worth (test knob): the batch goes through in many chunks
+            per = 8 * (n * n + n * m + r * n + n + f * r + f * r * n + f * r * v * m + (v * m) ** 2 + v * m)
+            os.environ["MPCX_RELAY_CAP_BYTES"] = str(int(3.5 * per))
+            try:
+                chunked = _run(ctx, data, interleave)
+            finally:
+                del os.environ["MPCX_RELAY_CAP_BYTES"]
+            for k in ("Phi", "Gamma", "H", "fvec"):
+                assert np.array_equal(chunked[k], base[k]), f"chunked relay: {k} differs"
+        if n == 8:
+            want = oracle_qp(orc, data)
+            for k in ("Phi", "Gamma", "H", "fvec"):
+                assert_close(got[k], want[k], f"relayed n{n} W={interleave} {k}")
+            c1 = _run(ctx, data, 1, want=("H",), hessian_algo=ffi.HESSIAN_CONTRACT)["H"]
+            cw = _run(ctx, data, interleave, want=("H",), hessian_algo=ffi.HESSIAN_CONTRACT)["H"]
+            assert np.array_equal(cw, c1), "matrix-core contraction: interleaved batch differs from interleave = 1"
+            W4 = rng.standard_normal((f * r, f * r))
+            kw = dict(W3=data["W3"], W4=W4, x0=data["x0"], ref=data["ref"], weights_mode=ffi.WEIGHTS_DENSE)
+            d1 = ctx.qp_build(A, B, C, f, v, interleave=1, **kw)
+            dw = ctx.qp_build(A, B, C, f, v, interleave=interleave, **kw)
+            for k in ("Phi", "Gamma", "H", "fvec"):
+                assert np.array_equal(dw[k], d1[k]), f"dense W4: {k} differs between interleave {interleave} and 1"
 
 
 @pytest.mark.parametrize("n,m,r,f,v", [(2, 1, 1, 20, 20), (4, 2, 3, 9, 4), (12, 4, 12, 6, 6), (8, 2, 2, 25, 25), (3, 1, 2, 7, 1),
