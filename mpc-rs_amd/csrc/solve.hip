@@ -7,6 +7,9 @@
 // the batched call reports the reference's Err("Matrix inversion failed") without aborting the batch.
 //   solve:  R = fvec (one column),        X = -H^-1 fvec = the optimal input sequence
 //   gain:   R = Gamma^T blockdiag(Q),     X = H^-1 Gamma^T W4 = the reference's gain_matrix
+#include <type_traits>
+#include <utility>
+
 #include "mpcx_internal.h"
 
 namespace mpcx {
@@ -247,6 +250,176 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs p, int ipb,
     }
 }
 
+// The same elimination for the reference's own horizon (v m = 20 unknowns; 20 right-hand sides for the gain of a
+// single-output plant, one for the solve) with every size a compile-time constant: lane i of a 32-lane group keeps row
+// i of [H | R] in REGISTERS (all loops unrolled, static register indices), and the only LDS traffic of a step is the
+// pivot row: the lane that owns it publishes its live columns, every lane of the group reads them back as a
+// broadcast.  That is 8 bytes of LDS traffic per updated element where solve_small_kernel moves 24 (it reads the pivot
+// element, reads its own and writes its own), and LDS bandwidth is what bounds that kernel.  HBM <-> registers goes
+// through an LDS staging area [element][instance] that the whole workgroup fills / drains with instance-fastest
+// accesses (one access = the same element of all `ipb` instances of the workgroup in the interleaved layouts).
+// Arithmetic, pivot choice and failure handling are those of solve_small_kernel, operation for operation.
+// RR > 0: R is Gamma (NRHS x NR per instance, NRHS = f RR) and the right-hand side Gamma^T blockdiag(Q) is formed while
+// the rows are pulled from the staging area; RR = 0: R is the NR x NRHS right-hand side itself.
+template <class F, int... K>
+__device__ __forceinline__ void for_each_index(F &f, std::integer_sequence<int, K...>) {
+    (f(std::integral_constant<int, K>{}), ...);
+}
+
+template <int NR, int NRHS, int RR>
+__global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb) {
+    constexpr int G = 32, NC = NR + NRHS, NCP = (NC + 1) & ~1;
+    constexpr int EH = NR * NR, ER = NR * NRHS, ES = EH > ER ? EH : ER;
+    static_assert(NR <= G, "one row per lane of a 32-lane group");
+    extern __shared__ __align__(16) double sm[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int ldi = ipb | 1;                 // odd leading dimension of the staging area: [element][instance]
+    double *stage = sm;
+    double *pbuf = sm + (((size_t)ES * ldi + 1) & ~(size_t)1);  // pivot rows: [group][NCP]
+    const long long b0 = (long long)blockIdx.x * ipb;
+    const int live = (p.batch - b0 < ipb) ? (int)(p.batch - b0) : ipb;
+
+    auto load = [&](const double *src, int E) {
+        if (p.W > 1) {  // instance fastest
+            const int step = nthreads / ipb, inst = tid % ipb;
+            const double *sp = src + elem_index(b0 + (inst < live ? inst : 0), 0, E, p.W);
+            if (inst < live)
+                for (int e = tid / ipb; e < E; e += step) stage[e * ldi + inst] = sp[(long long)e * p.W];
+        } else {        // instance-major: elements fastest
+            for (int t = tid; t < live * E; t += nthreads) {
+                const int inst = t / E, e = t - inst * E;
+                stage[e * ldi + inst] = src[(b0 + inst) * (long long)E + e];
+            }
+        }
+    };
+    const int g = tid / G, i = tid % G;
+    const bool active = g < live && i < NR;
+    const int gi = g < ipb ? g : 0, ii = i < NR ? i : 0;
+    double a[NC];
+
+    load(p.H, EH);
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < NR; ++j) a[j] = stage[(j * NR + ii) * ldi + gi];
+    lds_barrier();
+    load(p.R, ER);
+    lds_barrier();
+    if constexpr (RR == 0) {
+#pragma unroll
+        for (int c = 0; c < NRHS; ++c) a[NR + c] = stage[(c * NR + ii) * ldi + gi];
+    } else {
+        // right-hand side column c = (blk, a2), row i:  sum_a Gamma[blk RR + a][i] Q[a][a2]   (controller.rs:96, M^T W4)
+        double q[RR > 0 ? RR : 1][RR > 0 ? RR : 1];
+#pragma unroll
+        for (int a2 = 0; a2 < RR; ++a2)
+#pragma unroll
+            for (int aa = 0; aa < RR; ++aa) q[aa][a2] = p.Q[a2 * RR + aa];
+#pragma unroll
+        for (int c = 0; c < NRHS; ++c) {
+            const int blk = c / (RR > 0 ? RR : 1), a2 = c % (RR > 0 ? RR : 1);
+            double acc = 0.0;
+#pragma unroll
+            for (int aa = 0; aa < RR; ++aa) acc += stage[(ii * NRHS + blk * RR + aa) * ldi + gi] * q[aa][a2];
+            a[NR + c] = acc;
+        }
+    }
+    lds_barrier();  // the staging area is free again (the results go through it)
+
+    const int lane = tid & 63, gbase = lane - i;  // first lane of this group within the wavefront
+    double *prow_buf = pbuf + (size_t)gi * NCP;
+    bool done = false, failed = false;
+    int mycol = 0;
+    double mypiv = 1.0;
+    // One elimination step with the step index a compile-time constant, so that every inner loop has constant bounds
+    // (full unrolling, static register indices: the row never leaves the registers).
+    auto step = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        double cand = -1.0;
+        if (active && !done) {
+            const double x = fabs(a[k]);
+            cand = (x == x) ? x : INFINITY;  // a NaN must be picked (and then fail), not skipped
+        }
+        // maximum over the group: four exchanges inside rows of 16 lanes at ALU speed, one across the two rows
+        double best = cand;
+        best = fmax(best, dpp_f64<0xB1>(best));   // quad_perm [1,0,3,2]
+        best = fmax(best, dpp_f64<0x4E>(best));   // quad_perm [2,3,0,1]
+        best = fmax(best, dpp_f64<0x141>(best));  // row_half_mirror: quads pair up
+        best = fmax(best, dpp_f64<0x140>(best));  // row_mirror: halves of a row pair up
+        best = fmax(best, __shfl_xor(best, 16));
+        const unsigned long long votes = __ballot(cand == best && active && !done);
+        const unsigned mine = (unsigned)(votes >> gbase);
+        const int prow = mine ? __ffs((int)mine) - 1 : 0;
+        if (!(best > 0.0) || !isfinite(best)) failed = true;  // zero or non-finite pivot: the reference's inversion error
+        const bool is_piv = (i == prow);
+        constexpr int J0 = k & ~1;  // 16-byte pairs: an odd k republishes column k - 1 as well (never read)
+        if (is_piv) {
+#pragma unroll
+            for (int j = J0; j < NC; j += 2)
+                *(double2 *)(prow_buf + j) = make_double2(a[j], j + 1 < NC ? a[j + 1 < NC ? j + 1 : j] : 0.0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double piv = prow_buf[k];
+        if (is_piv && !failed) { done = true; mycol = k; mypiv = a[k]; }
+        const double m = (active && !is_piv && !failed) ? a[k] / piv : 0.0;
+        // a[j] -= m P[j] for j > k, the pivot row read back in chunks of CH pairs (the whole row at once would need
+        // as many registers again as the lane's own row)
+        constexpr int CH = 5;
+#pragma unroll
+        for (int j0 = (k + 1) & ~1; j0 < NC; j0 += 2 * CH) {
+            double2 t[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (j0 + 2 * u < NC) t[u] = *(const double2 *)(prow_buf + j0 + 2 * u);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = j0 + 2 * u;
+                if (j > k && j < NC) a[j < NC ? j : 0] -= m * t[u].x;
+                if (j + 1 > k && j + 1 < NC) a[j + 1 < NC ? j + 1 : 0] -= m * t[u].y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for_each_index(step, std::make_integer_sequence<int, NR>{});
+    // the row that was the pivot of step k holds unknown k: x[k][c] = a[row][NR + c] / a[row][k]
+    if (active) {
+        const double sign = p.negate ? -1.0 : 1.0;
+        const double inv = 1.0 / mypiv;
+        const int row = failed ? i : mycol;
+#pragma unroll
+        for (int c = 0; c < NRHS; ++c)
+            stage[(c * NR + row) * ldi + g] = failed ? __longlong_as_double(0x7ff8000000000000LL) : sign * (a[NR + c] * inv);
+        if (p.info && i == 0) p.info[b0 + g] = failed ? 1 : 0;
+    }
+    lds_barrier();
+    if (p.W > 1) {
+        const int step = nthreads / ipb, inst = tid % ipb;
+        double *xp = p.X + elem_index(b0 + (inst < live ? inst : 0), 0, ER, p.W);
+        if (inst < live)
+            for (int e = tid / ipb; e < ER; e += step) xp[(long long)e * p.W] = stage[e * ldi + inst];
+    } else {
+        for (int t = tid; t < live * ER; t += nthreads) {
+            const int inst = t / ER, e = t - inst * ER;
+            p.X[(b0 + inst) * (long long)ER + e] = stage[e * ldi + inst];
+        }
+    }
+}
+
+template <int NR, int NRHS, int RR>
+int launch_rows(const SolveArgs &a, hipStream_t s) {
+    constexpr int NC = NR + NRHS, NCP = (NC + 1) & ~1, ES = NR * (NR > NRHS ? NR : NRHS);
+    const int ipb = 8;  // 64-byte runs in the interleaved layouts; measured: 4 and 16 instances are 2 % and 7 % slower
+    const long long blocks = (a.batch + ipb - 1) / ipb;
+    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    const size_t lds = ((((size_t)ES * (ipb | 1) + 1) & ~(size_t)1) + (size_t)ipb * NCP) * sizeof(double);
+    hipLaunchKernelGGL((solve_rows_kernel<NR, NRHS, RR>), dim3((unsigned)blocks), dim3(ipb * 32), lds, s, a, ipb);
+    return (int)hipGetLastError();
+}
+
 // R[c][(i, a2)] = sum_a Gamma[(i, a)][c] Q[a][a2]  (Gamma^T blockdiag(Q)), written to `out` in the batch layout
 __global__ __launch_bounds__(256) void gamma_t_q_kernel(const double *Gamma, const double *Q, double *out, long long batch,
                                                         long long W, int m, int r, int f, int v) {
@@ -289,6 +462,9 @@ int launch_small(const SolveArgs &a, hipStream_t s) {
 }
 
 int launch_solve(const SolveArgs &a, hipStream_t s) {
+    // the reference's horizon with rows in registers: gain of a single-output plant, and the solve
+    if (a.nrow == 20 && a.nrhs == 20 && a.Q && a.r == 1 && a.R != a.X) return launch_rows<20, 20, 1>(a, s);
+    if (a.nrow == 20 && a.nrhs == 1 && !a.Q && a.R != a.X) return launch_rows<20, 1, 0>(a, s);
     if (a.nrow <= 64) {
         const int rc = a.nrow <= 16 ? launch_small<16>(a, s) : a.nrow <= 32 ? launch_small<32>(a, s) : launch_small<64>(a, s);
         if (rc != MPCX_ERR_UNSUPPORTED) return rc;

@@ -70,6 +70,39 @@ def test_singular_instances_are_flagged_not_fatal(ctx):
     assert info[0] == 1 and st == orc.ORC_ERR_INVERSION
 
 
+@pytest.mark.parametrize("il", [0, 1, 64])
+@pytest.mark.parametrize("batch", [1, 7, 8, 61])
+def test_reference_horizon_rows_in_registers(ctx, il, batch):
+    """20 unknowns with 20 right-hand sides (gain, single output) or one (solve): the register-resident elimination.
+    Row exchanges at several steps, singular / NaN instances flagged, ragged last workgroup, every layout."""
+    rng = np.random.default_rng(100 * batch + il)
+    vm = fr = 20
+    H = rng.standard_normal((batch, vm, vm))
+    H[:, 0, 0] = 0.0            # exchange in the first step
+    H[:, 5, :5] = 0.0           # row 5 cannot be a pivot before step 5
+    H[:, 5, 5] = 1e-9           # and is a poor one there
+    Gamma = rng.standard_normal((batch, fr, vm))
+    q = np.array([[2.5]])
+    fv = rng.standard_normal((batch, vm))
+    bad = [b for b in (2, 5) if b < batch]
+    if 2 < batch:
+        H[2, :, 7] = 0.0        # zero column: singular
+    if 5 < batch:
+        H[5, 3, 4] = np.nan
+    good = [b for b in range(batch) if b not in bad]
+    gain, info = ctx.qp_gain(H, Gamma, q, 1, 1, 20, 20, interleave=il)
+    assert list(np.nonzero(info)[0]) == bad
+    assert np.all(np.isnan(gain[bad])) and np.all(np.isfinite(gain[good]))
+    u, info_s = ctx.qp_solve(H, fv, 1, interleave=il)
+    assert list(np.nonzero(info_s)[0]) == bad
+    assert np.all(np.isnan(u[bad])) and np.all(np.isfinite(u[good]))
+    for b in good:
+        cond = np.linalg.cond(H[b])
+        want = np.linalg.solve(H[b], Gamma[b].T * q[0, 0])
+        assert rel_fro(gain[b], want) <= 1e-11 * cond, f"gain of instance {b}"
+        assert rel_fro(u[b], -np.linalg.solve(H[b], fv[b])) <= 1e-11 * cond, f"solve of instance {b}"
+
+
 @pytest.mark.parametrize("vm,m,fr,r,il", [(65, 1, 70, 1, 1), (100, 2, 150, 3, 1), (130, 1, 140, 1, 0), (200, 4, 600, 12, 1), (48, 1, 500, 1, 1)])
 def test_large_systems_blocked_solver(ctx, vm, m, fr, r, il):
     """Beyond 64 unknowns (or right-hand sides that do not fit LDS): the blocked solver on a device workspace."""
