@@ -248,28 +248,32 @@ __device__ __forceinline__ void w3_loader_run(const double *gW3, double *sW3, co
     else w3_loader_sweep<1>(gW3, sW3, band, v, m, lw, (unsigned)ltid);
 }
 
-// One workgroup per column block bb of W3 ((v m) x (v m), column-major): how far its non-zeros (NaNs included) reach
-// above and below row bb m, folded into reach[0] / reach[1] by atomic maximum (the caller sets both to INT_MIN first).
+// One workgroup per column of W3 ((v m) x (v m), column-major; column block bb = column / m): how far the column's
+// non-zeros (NaNs included) reach above and below row bb m, folded into reach[0] / reach[1] by atomic maximum (the
+// caller sets both to INT_MIN first).
 __global__ __launch_bounds__(256) void w3_band_kernel(const double *__restrict__ W3, int v, int m, int *reach) {
     __shared__ int slo, shi;
-    const int bb = blockIdx.x, VM = v * m;
+    const int col = blockIdx.x, VM = v * m, bb = col / m;
     if (threadIdx.x == 0) { slo = VM; shi = 0; }
     __syncthreads();
     int lo = VM, hi = 0;
-    const double *src = W3 + (long long)bb * VM * m;
-    for (int e = threadIdx.x; e < VM * m; e += 256) {
-        if (!(src[e] == 0.0)) {
-            const int row = e % VM;
+    const double *src = W3 + (long long)col * VM;
+    for (int row = threadIdx.x; row < VM; row += 256) {
+        if (!(src[row] == 0.0)) {
             lo = row < lo ? row : lo;
             hi = row + 1 > hi ? row + 1 : hi;
         }
     }
-    atomicMin(&slo, lo);
-    atomicMax(&shi, hi);
+    if (hi > lo) {
+        atomicMin(&slo, lo);
+        atomicMax(&shi, hi);
+    }
     __syncthreads();
     if (threadIdx.x == 0 && shi > slo) {
-        atomicMax(&reach[0], bb * m - slo);
-        atomicMax(&reach[1], shi - bb * m);
+        // atomics on one address serialise in the L2: look first, most columns of a banded W3 have nothing to add
+        const int up = bb * m - slo, down = shi - bb * m;
+        if (__atomic_load_n(&reach[0], __ATOMIC_RELAXED) < up) atomicMax(&reach[0], up);
+        if (__atomic_load_n(&reach[1], __ATOMIC_RELAXED) < down) atomicMax(&reach[1], down);
     }
 }
 
@@ -768,7 +772,7 @@ int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s) {
     if (a.H && a.W3 && a.w3win && (wcnt & 1) == 0 && ((uintptr_t)a.W3 & 15) == 0 && a.w3win_bytes >= 2 * sizeof(int)) {
         hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.w3win, INT_MIN, 2, s);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(w3_band_kernel, dim3((unsigned)a.v), dim3(256), 0, s, a.W3, a.v, a.m, (int *)a.w3win);
+        hipLaunchKernelGGL(w3_band_kernel, dim3((unsigned)(a.v * a.m)), dim3(256), 0, s, a.W3, a.v, a.m, (int *)a.w3win);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     } else {
