@@ -28,6 +28,32 @@ def test_library_exports_every_declared_symbol():
         assert e.value.code == ffi.ERR_NO_DEVICE
 
 
+def test_rust_sys_crate_declares_the_same_abi():
+    """rust/mpcx-sys cannot be compiled in this image; at least its declarations must follow the header: the same entry
+    points with the same number of arguments, the same struct fields in the same order, the same constants."""
+    header = open(os.path.join(ROOT, "include", "mpcx.h")).read()
+    rust = open(os.path.join(ROOT, "rust", "mpcx-sys", "src", "lib.rs")).read()
+    header_nc = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    c_fns = {m.group(1): m.group(2) for m in re.finditer(r"\b(mpcx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header_nc, flags=re.S)}
+    r_fns = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (mpcx_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", rust, flags=re.S)}
+    assert set(c_fns) == set(r_fns) == set(ffi.EXPORTS), set(c_fns) ^ set(r_fns)
+    for name, args in c_fns.items():
+        n_c = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        n_r = 0 if not r_fns[name].strip() else r_fns[name].count(",") + 1
+        assert n_c == n_r, f"{name}: {n_c} arguments in the header, {n_r} in the Rust declaration"
+    for struct in ("mpcx_dims", "mpcx_stats"):
+        c_body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header_nc, flags=re.S).group(1)
+        c_fields = [f.lower() for f in re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*;", c_body)]
+        r_body = re.search(r"pub struct %s \{(.*?)\}" % struct, rust, flags=re.S).group(1)
+        r_fields = re.findall(r"pub ([a-z_0-9]+):", r_body)
+        assert c_fields == r_fields, (struct, c_fields, r_fields)
+    for name, value in re.findall(r"#define (MPCX_[A-Z_]+) \(?(-?\d+)\)?", header):
+        if name == "MPCX_VERSION":
+            continue
+        m = re.search(r"pub const %s: [a-z_0-9]+ = (-?\d+);" % name, rust)
+        assert m and int(m.group(1)) == int(value), f"{name} differs between the header and the Rust crate"
+
+
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(ffi.Dims) == 8 * 4 + 3 * 8
     assert ctypes.sizeof(ffi.Stats) == 48
