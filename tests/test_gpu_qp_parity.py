@@ -107,6 +107,34 @@ def test_workgroup_kernel_sparse_input_weight(ctx, n, m, r, f, v, pattern):
         assert_close(got, oracle_qp(orc, data, want=("H",))["H"], f"wg sparse W3 {pattern} n{n} m{m} r{r} f{f} v{v} H")
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_workgroup_kernel_random_shapes(ctx, seed):
+    """Seeded random shapes on the workgroup kernels: strides 1, 2 and 4 of the recurrences, held inputs (f > v),
+    odd and even v m, output subsets, banded and dense W3."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(7, 17))
+    m = int(rng.integers(1, 5))
+    r = int(rng.integers(1, 7))
+    f = int(rng.integers(1, 49))
+    v = int(rng.integers(1, f + 1))
+    batch = int(rng.integers(1, 6))
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    if seed % 3 == 0:
+        w3, _ = synth.block_weights(m, r, v, 0.3, 0.7, 1.0, all_elements=bool(seed % 2))
+    else:
+        w3 = rng.standard_normal((v * m, v * m))
+    data = dict(A=A, B=B, C=C, W3=w3, Q=rng.standard_normal((r, r)), x0=rng.standard_normal((batch, n)),
+                ref=rng.standard_normal((batch, f * r)), f=f, v=v)
+    want = oracle_qp(orc, data)
+    got = _run(ctx, data, 1)
+    for k in ("Phi", "Gamma", "H", "fvec"):
+        assert_close(got[k], want[k], f"wg random n{n} m{m} r{r} f{f} v{v} {k}")
+    sub = ("Phi", "H") if seed % 2 else ("Gamma",)
+    part = _run(ctx, data, 1, want=sub)
+    for k in sub:
+        assert np.array_equal(part[k], got[k]), f"subset {sub}: {k} differs from the full call"
+
+
 def test_quadrotor_and_long_horizon_workloads(ctx):
     for name, batch in (("quadrotor", 6), ("long", 2)):
         data = synth.make_batch(name, batch)
