@@ -6,4 +6,14 @@
 //! Written against `include/mpcx.h`; this image has no Rust toolchain, so the crate has not been compiled.  The
 //! same calls, in the same order, are what `mpc-rs_amd/host/control_sys_rs.hpp` (C++, compiled and tested on the
 //! GPU) makes.
-pub mod control;
+/// The reference's `control` module tree (src/control.rs:1-4) plus the additive `batch`.
+pub mod control {
+    pub mod batch;
+    pub mod controller;
+    mod device;
+    pub mod model;
+    #[path = "rollout_host.rs"]
+    pub mod simulator;
+    #[path = "pulse.rs"]
+    pub mod trajectory;
+}
