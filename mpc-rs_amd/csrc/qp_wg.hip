@@ -67,7 +67,7 @@ __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v
     o = u;
     L.Hp = o; o += 2 * v * m * m;   // column block of H (without W3), ping-pong: [slot][i*m + j][a]
     L.W3r = o; o += 2 * v * m * m;  // ring of two column blocks of W3: [slot][j][row]
-    L.Tab = o; o += (f > v) ? 3 * v * m * m : 0;  // held-input case only: last column, last row, Toeplitz seed row
+    L.Tab = o; o += (f > v) ? 2 * v * m * m : 0;  // held-input case only: first swept column and Toeplitz seed row
     L.total = o > end1 ? o : end1;
     return L;
 }
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void w3_band_kernel(const double *__restrict__
 
 // HM, HR, ITEMS > 0: the H sweep is specialised for m = HM, r = HR with up to ITEMS (block row, column) pairs per
 // thread held in registers (needs v m <= ITEMS * kCompute).  HM = 0: generic sweep, operands read from LDS.
-// HELD: f > v (the last block column is the held-input column); false removes the table look-ups and the direct sums
+// HELD: f > v (the last block column is the held-input column); false removes the table look-ups
 // from the specialised sweep, and with them a dozen live registers.
 template <int HM, int HR, int ITEMS, bool HELD>
 __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
@@ -571,8 +571,9 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     //      new one goes to the other half; the loader wave streams the next block of W3 into its ring meanwhile.
     //      sHp is indexed [i*m + j][a]: lanes along the block rows, so reads and writes are conflict-free.
     //      What is swept is the Gram matrix Ht of the plain-shift columns, for which the recurrence holds for every
-    //      block with Ht[v][.] = 0 when f = v.  When f > v the row Ht[v-1][.] is seeded from a table, and the last
-    //      block row and column of H (which involve the held-input column) are taken from two more tables. ----
+    //      block with Ht[v][.] = 0 when f = v.  When f > v the column Ht[.][v-1] and the row Ht[v-1][.] come from two
+    //      tables, and the last block row and column of H (which involve the held-input column) are left out of the
+    //      sweep and stored after it. ----
     STAMP(4);
     if (p.H) {
         lds_barrier();  // z and the inputs are dead: their LDS becomes the sweep's buffers
@@ -586,16 +587,19 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         }
         const int bsz = m * m, tsz = v * bsz;
         const bool held = HM > 0 ? HELD : nl > 1;
+        // f > v: the sweep runs on the Gram matrix Ht of plain-shift columns.  Its column block v-1 (where the sweep
+        // starts) and its block row v-1 (the seed of every later column) are short direct sums (f - v + 1 terms), kept
+        // in two tables.  The last block row and column of H itself, which involve the held-input column, are not part
+        // of the sweep at all: they are summed and stored after it.
         if (held) {
-            for (int t = tid; t < 3 * tsz; t += kWgBlock) {
+            for (int t = tid; t < 2 * tsz; t += kWgBlock) {
                 const int which = t / tsz, rem = t - which * tsz, blk = rem / bsz, ij = rem - blk * bsz;
                 const int i = ij / m, j = ij - i * m;
-                sTab[t] = which == 0   ? h_direct(sG, sS, sQG, sQS, blk, v - 1, i, j, f, v, r, FR, nl, true)
-                          : which == 1 ? h_direct(sG, sS, sQG, sQS, v - 1, blk, i, j, f, v, r, FR, nl, true)
-                                       : h_direct(sG, sS, sQG, sQS, v - 1, blk, i, j, f, v, r, FR, nl, false);
+                sTab[t] = which == 0 ? h_direct(sG, sS, sQG, sQS, blk, v - 1, i, j, f, v, r, FR, nl, false)
+                                     : h_direct(sG, sS, sQG, sQS, v - 1, blk, i, j, f, v, r, FR, nl, false);
             }
         }
-        const double *tabCol = sTab, *tabRow = sTab + tsz, *tabSeed = sTab + 2 * tsz;
+        const double *tabFirst = sTab, *tabSeed = sTab + tsz;
         double *gH = p.H + b * (long long)VM * VM;
 
         if constexpr (HM > 0) {
@@ -659,8 +663,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                         const bool lastrow = (aa == v - 1);
                         if (first && held) {
 #pragma unroll
-                            for (int i = 0; i < HM; ++i)
-                                acc[ic][i] = h_direct(sG, sS, sQG, sQS, aa, bb, i, j, f, v, HR, FR, nl, false);
+                            for (int i = 0; i < HM; ++i) acc[ic][i] = tabFirst[(aa * HM + i) * HM + j];
                         } else {
 #pragma unroll
                             for (int q = 0; q < HR; ++q)
@@ -683,11 +686,9 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
 #pragma unroll
                         for (int i = 0; i < HM; ++i) {
                             cur[(i * HM + j) * v + aa] = acc[ic][i];
-                            out[i] = acc[ic][i];
-                            if (held && first) out[i] = tabCol[(aa * HM + i) * HM + j];
-                            else if (held && lastrow) out[i] = tabRow[(bb * HM + i) * HM + j];
-                            out[i] += w3v[ic][i];
+                            out[i] = acc[ic][i] + w3v[ic][i];
                         }
+                        if (held && (first || lastrow)) continue;  // H's last block row / column: after the sweep
                         if constexpr (HM % 2 == 0) {
 #pragma unroll
                             for (int i = 0; i < HM; i += 2) *(double2 *)(dst + i) = make_double2(out[i], out[i + 1]);
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                         for (int i = 0; i < m; ++i) {
                             double acc;
                             if (first && held) {
-                                acc = h_direct(sG, sS, sQG, sQS, aa, bb, i, j, f, v, r, FR, nl, false);
+                                acc = tabFirst[(aa * m + i) * m + j];
                             } else {
                                 const double pv = prev[(i * m + j) * v + an];
                                 acc = (first || lastrow) ? 0.0 : pv;
@@ -729,13 +730,25 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                                 if (held && lastrow) acc = tabSeed[(bb * m + i) * m + j];
                             }
                             cur[(i * m + j) * v + aa] = acc;
-                            if (held && first) acc = tabCol[(aa * m + i) * m + j];
-                            else if (held && lastrow) acc = tabRow[(bb * m + i) * m + j];
+                            if (held && (first || lastrow)) continue;  // H's last block row / column: after the sweep
                             gH[(long long)(bb * m + j) * VM + aa * m + i] = acc + w3[j * VM + aa * m + i];
                         }
                     }
                     lds_barrier();
                 }
+            }
+        }
+        // f > v: last block column (which = 0) and last block row (which = 1) of H, with the held-input column S in
+        // place of a plain shift, summed directly (f - v + 1 terms each) and stored with their share of W3.  The two
+        // meet in the corner block with the same value.
+        if (held) {
+            for (int t = tid; t < 2 * tsz; t += kWgBlock) {
+                const int which = t / tsz, rem = t - which * tsz, blk = rem / bsz, ij = rem - blk * bsz;
+                const int i = ij / m, j = ij - i * m;
+                const int row = (which == 0 ? blk : v - 1) * m + i, col = (which == 0 ? v - 1 : blk) * m + j;
+                const double hv = which == 0 ? h_direct(sG, sS, sQG, sQS, blk, v - 1, i, j, f, v, r, FR, nl, true)
+                                             : h_direct(sG, sS, sQG, sQS, v - 1, blk, i, j, f, v, r, FR, nl, true);
+                gH[(long long)col * VM + row] = hv + p.W3[(long long)col * VM + row];
             }
         }
     }
