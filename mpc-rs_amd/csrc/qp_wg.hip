@@ -44,6 +44,15 @@ struct WgLds {
 
 // G, S, QG, QS live for the whole kernel.  The inputs, the recurrence states and z are dead once fvec is out, and
 // the H sweep's buffers (two column blocks of H, two of W3) reuse their space.
+// Steps the recurrences advance per iteration (4, 2 or 1): as many as give every task of an iteration its own compute
+// thread and divide f.  with_s: the s = Phi x0 - ref tasks ride along (fvec requested).
+__host__ __device__ inline int wg_stride(int n, int m, int r, int f, bool with_s) {
+    const int per = r * m + r * n + (with_s ? r : 0), nW = n * m;
+    if (f % 4 == 0 && 4 * per + nW <= kCompute) return 4;
+    if (f % 2 == 0 && 2 * per + nW <= kCompute) return 2;
+    return 1;
+}
+
 __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v) {
     WgLds L;
     int o = 0;
@@ -62,7 +71,8 @@ __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v
     L.Pst = o; o += 2 * r * n;   // Phi state, ping-pong
     L.Sr = o; o += fr;           // ref, then Phi x0 - ref
     L.Z = o; o += fr;            // Q (Phi x0 - ref)
-    L.Pow = o; o += 3 * n * n + 3 * r * n + 4 * n;  // strided recurrences: A^2..A^4, C A..C A^3, A x0..A^4 x0
+    // strided recurrences only (the stride without the s tasks is the larger of the two): A^2..A^4, C A..C A^3, A x0..A^4 x0
+    L.Pow = o; o += wg_stride(n, m, r, f, false) > 1 ? 3 * n * n + 3 * r * n + 4 * n : 0;
     const int end1 = o;
     o = u;
     L.Hp = o; o += 2 * v * m * m;   // column block of H (without W3), ping-pong: [slot][i*m + j][a]
@@ -77,15 +87,23 @@ __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v
 // held-input column, X_(v-1)(i2) = S_(i2-v+1) (the cumulated Markov blocks); without it every column is a plain shift.
 __device__ inline double h_direct(const double *sG, const double *sS, const double *sQG, const double *sQS, int aa,
                                   int bb, int i, int j, int f, int v, int r, int FR, int nl, bool use_s) {
-    double acc = 0.0;
     const bool la = use_s && (aa == v - 1), lb = use_s && (bb == v - 1);
     const int i0 = aa > bb ? aa : bb;
-    for (int i2 = i0; i2 < f; ++i2) {
-        const double *ga = la ? (sS + i * nl * r + (i2 - (v - 1)) * r) : (sG + i * FR + (i2 - aa) * r);
-        const double *qb = lb ? (sQS + j * nl * r + (i2 - (v - 1)) * r) : (sQG + j * FR + (i2 - bb) * r);
-        for (int q = 0; q < r; ++q) acc += ga[q] * qb[q];
+    // both operands are contiguous over (i2, q): one dot product of length (f - i0) r
+    const double *ga = la ? (sS + i * nl * r + (i0 - (v - 1)) * r) : (sG + i * FR + (i0 - aa) * r);
+    const double *qb = lb ? (sQS + j * nl * r + (i0 - (v - 1)) * r) : (sQG + j * FR + (i0 - bb) * r);
+    const int len = (f - i0) * r;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    int t = 0;
+    for (; t + 7 < len; t += 8) {  // eight independent LDS read pairs per round: one latency, not eight
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = ga[t + u]; y[u] = qb[t + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u & 3] += x[u] * y[u];
     }
-    return acc;
+    for (; t < len; ++t) a[t & 3] += ga[t] * qb[t];
+    return (a[0] + a[1]) + (a[2] + a[3]);
 }
 
 // The loader waves' W3 pipeline.  Step s of the sweep (s = 0 .. v-1) uses column block v-1-s of W3 (wcnt doubles,
@@ -342,9 +360,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         // threads allow it a step advances the states by A^st (st = 4 or 2) and produces the st Markov blocks, Phi
         // blocks and s vectors in between from the same state: G_(k+j) = (C A^j) W_k, Phi block k+j = P_k A^(j+1),
         // s_(k+j) = P_k (A^(j+1) x0) - ref_(k+j).  Still one dot product per thread and step, f / st steps.
-        int st = 1;
-        if (f % 4 == 0 && 4 * (nG + nP + nS) + nW <= kCompute) st = 4;
-        else if (f % 2 == 0 && 2 * (nG + nP + nS) + nW <= kCompute) st = 2;
+        const int st = wg_stride(n, m, r, f, nS > 0);
         double *sPow = lds + L.Pow, *sCA = sPow + 3 * n * n, *sAjx = sCA + 3 * r * n;
         auto Apow = [&](int j) -> const double * { return j == 1 ? sA : sPow + (j - 2) * n * n; };   // A^j, j = 1..4
         auto CApow = [&](int j) -> const double * { return j == 0 ? sC : sCA + (j - 1) * r * n; };  // C A^j, j = 0..3

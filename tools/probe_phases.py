@@ -6,7 +6,9 @@ from mpc_rs_amd import ffi, layout as L, synth
 name = sys.argv[1]; count = int(sys.argv[2]); want = sys.argv[3].split("+")
 dev = torch.device("cuda", 0); ctx = ffi.Context(0)
 wl = synth.WORKLOADS[name]; n, m, r, f, v = wl["n"], wl["m"], wl["r"], wl["f"], wl["v"]
-d = synth.make_batch(name, count); il = 1
+if len(sys.argv) > 5:  # optional horizon override: f v
+    f, v = int(sys.argv[4]), int(sys.argv[5])
+d = synth.make_batch(name, count, f=f, v=v); il = 1
 to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 bufs = {k: to(L.pack(d[k], il)) for k in ("A", "B", "C")}
 bufs["x0"] = to(L.pack(d["x0"].reshape(count, n, 1), il)); bufs["ref"] = to(L.pack(d["ref"].reshape(count, f * r, 1), il))
