@@ -106,6 +106,47 @@ __device__ inline double h_direct(const double *sG, const double *sS, const doub
     return (a[0] + a[1]) + (a[2] + a[3]);
 }
 
+// The whole M x M block (aa, bb) at once: out[i][j] as h_direct would give it (up to the order of the partial sums).
+// Every operand read serves M multiply-adds instead of one, which is what matters: the direct sums are bound by LDS
+// reads.  Two terms of the sum are in flight together.
+template <int M>
+__device__ __forceinline__ void h_direct_block(const double *sG, const double *sS, const double *sQG, const double *sQS, int aa,
+                                               int bb, int f, int v, int r, int FR, int nl, bool use_s, double (&out)[M][M]) {
+    const bool la = use_s && (aa == v - 1), lb = use_s && (bb == v - 1);
+    const int i0 = aa > bb ? aa : bb;
+    const double *ga = la ? (sS + (i0 - (v - 1)) * r) : (sG + (i0 - aa) * r);
+    const double *qb = lb ? (sQS + (i0 - (v - 1)) * r) : (sQG + (i0 - bb) * r);
+    const int sa = la ? nl * r : FR, sb = lb ? nl * r : FR;  // distance between the vectors of two columns
+    const int len = (f - i0) * r;
+    double acc0[M][M], acc1[M][M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) acc0[i][j] = acc1[i][j] = 0.0;
+    int t = 0;
+    for (; t + 1 < len; t += 2) {
+        double x0[M], x1[M], y0[M], y1[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) { x0[i] = ga[i * sa + t]; x1[i] = ga[i * sa + t + 1]; }
+#pragma unroll
+        for (int j = 0; j < M; ++j) { y0[j] = qb[j * sb + t]; y1[j] = qb[j * sb + t + 1]; }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) { acc0[i][j] += x0[i] * y0[j]; acc1[i][j] += x1[i] * y1[j]; }
+    }
+    if (t < len) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc0[i][j] += ga[i * sa + t] * qb[j * sb + t];
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) out[i][j] = acc0[i][j] + acc1[i][j];
+}
+
 // The loader waves' W3 pipeline.  Step s of the sweep (s = 0 .. v-1) uses column block v-1-s of W3 (wcnt doubles,
 // contiguous).  A block moves as 16-byte pairs in slots of 64 pairs (1 KiB, one load instruction of a wave); slot g
 // of every block belongs to loader wave g % kLoaders.  A wave fetches its slots of a block into registers NB steps
@@ -607,7 +648,19 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         // starts) and its block row v-1 (the seed of every later column) are short direct sums (f - v + 1 terms), kept
         // in two tables.  The last block row and column of H itself, which involve the held-input column, are not part
         // of the sweep at all: they are summed and stored after it.
-        if (held) {
+        if constexpr (HM > 0) {
+            if (held) {  // one block per thread
+                for (int t = tid; t < 2 * v; t += kWgBlock) {
+                    const int which = t / v, blk = t - which * v;
+                    double blkv[HM][HM];
+                    h_direct_block<HM>(sG, sS, sQG, sQS, which == 0 ? blk : v - 1, which == 0 ? v - 1 : blk, f, v, r, FR, nl, false, blkv);
+#pragma unroll
+                    for (int i = 0; i < HM; ++i)
+#pragma unroll
+                        for (int j = 0; j < HM; ++j) sTab[which * tsz + (blk * HM + i) * HM + j] = blkv[i][j];
+                }
+            }
+        } else if (held) {
             for (int t = tid; t < 2 * tsz; t += kWgBlock) {
                 const int which = t / tsz, rem = t - which * tsz, blk = rem / bsz, ij = rem - blk * bsz;
                 const int i = ij / m, j = ij - i * m;
@@ -757,7 +810,23 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         // f > v: last block column (which = 0) and last block row (which = 1) of H, with the held-input column S in
         // place of a plain shift, summed directly (f - v + 1 terms each) and stored with their share of W3.  The two
         // meet in the corner block with the same value.
-        if (held) {
+        if constexpr (HM > 0) {
+            if (held) {
+                for (int t = tid; t < 2 * v; t += kWgBlock) {
+                    const int which = t / v, blk = t - which * v;
+                    const int ba = which == 0 ? blk : v - 1, bbk = which == 0 ? v - 1 : blk;  // block row, block column
+                    double blkv[HM][HM];
+                    h_direct_block<HM>(sG, sS, sQG, sQS, ba, bbk, f, v, r, FR, nl, true, blkv);
+#pragma unroll
+                    for (int j = 0; j < HM; ++j)
+#pragma unroll
+                        for (int i = 0; i < HM; ++i) {
+                            const long long e = (long long)(bbk * HM + j) * VM + ba * HM + i;
+                            gH[e] = blkv[i][j] + p.W3[e];
+                        }
+                }
+            }
+        } else if (held) {
             for (int t = tid; t < 2 * tsz; t += kWgBlock) {
                 const int which = t / tsz, rem = t - which * tsz, blk = rem / bsz, ij = rem - blk * bsz;
                 const int i = ij / m, j = ij - i * m;
