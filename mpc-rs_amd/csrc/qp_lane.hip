@@ -16,7 +16,7 @@
 //
 // Two instantiation styles of one body:
 //   F = V = 0   horizons are run-time values; the Markov blocks and z live in LDS, one column of slots per lane.
-//   F, V > 0    horizons are compile-time; every loop unrolls, the Markov blocks and z live in registers and the
+//   F, V > 0    horizons are compile-time; every loop unrolls, the Markov blocks and z live in registers (no LDS) and the
 //               instruction stream is little more than the FMAs and the stores.
 // Addressing: every output is walked with a running pointer (wave-uniform when UNI) plus a fixed 32-bit lane
 // offset, so a store costs one vector instruction and a scalar pointer bump.
@@ -43,7 +43,7 @@ struct LaneOut {
 // tile offset is wave-uniform and each access is "scalar base + 32-bit lane offset".
 // OUT: 0 = test the output pointers at run time; 15 = all four outputs are present (no tests in the stream).
 template <int N, int M, int R, bool UNI, int F, int V, int OUT>
-__global__ __launch_bounds__(kLaneBlock, (F > 0 ? 4 : 1)) void qp_lane_kernel(const double *__restrict__ gA, const double *__restrict__ gB,
+__global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(const double *__restrict__ gA, const double *__restrict__ gB,
                                                              const double *__restrict__ gC,
                                                              const double *__restrict__ gW3,
                                                              const double *__restrict__ gW4,
@@ -70,13 +70,14 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 4 : 1)) void qp_lane_kernel(co
 #define AT(base, e) (*(double *)((base) + (long long)(e) * stride + lb))
 #define HERE(ptr) (*(double *)((ptr) + lb))
 
-    // z always lives in LDS (with a compile-time horizon it is the only LDS use: F R slots per lane), which keeps
-    // the register-resident variant within 128 VGPRs, i.e. four waves per SIMD.
+    // With a compile-time horizon z lives in registers as well: no LDS at all, 144 VGPRs for n = 4 (three waves per
+    // SIMD).  Measured against z in LDS at four waves per SIMD: 1.433 vs 1.454 ms for 2^20 two-mass instances.
     double greg[STATIC ? F * R * M : 1];
+    double zreg[STATIC ? F * R : 1];
     const int zbase = STATIC ? 0 : f * R * M;
 #define LG(k, a, c) \
     (*(STATIC ? &greg[STATIC ? (((k) * R + (a)) * M + (c)) : 0] : &lds[(((k) * R + (a)) * M + (c)) * kLaneBlock + tid]))
-#define LZ(i, a) lds[(zbase + (i) * R + (a)) * kLaneBlock + tid]
+#define LZ(i, a) (*(STATIC ? &zreg[STATIC ? ((i) * R + (a)) : 0] : &lds[(zbase + (i) * R + (a)) * kLaneBlock + tid]))
 
     double A[N][N], Bm[N][M], Cm[R][N];
     {
@@ -411,7 +412,7 @@ int launch_one(const QpArgs &a, hipStream_t s) {
     const bool all = a.Phi && a.Gamma && a.H && a.fvec;
     if constexpr (M == 1 && R == 1 && (N == 2 || N == 4)) {
         if (uni && all && a.f == 20 && a.v == 20)
-            return launch_k<N, M, R, true, 20, 20, 15>(a, (size_t)20 * R * kLaneBlock * sizeof(double), (unsigned)blocks, s);
+            return launch_k<N, M, R, true, 20, 20, 15>(a, 0, (unsigned)blocks, s);
     }
     const size_t zh = (size_t)a.f * R > (size_t)a.v * M * M ? (size_t)a.f * R : (size_t)a.v * M * M;
     const size_t slots = (size_t)a.f * R * M + zh;  // Markov blocks + max(z, one column block of H)
