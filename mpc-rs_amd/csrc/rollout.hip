@@ -336,8 +336,10 @@ int launch_group_np(const RolloutArgs &a, hipStream_t s) {
 template <int G>
 int launch_group_one(const RolloutArgs &a, hipStream_t s) {
     if constexpr (G == 16) {
-        if (a.m <= 4 && a.n <= 8) return launch_group_np<16, 8, 4>(a, s);
-        if (a.m <= 4 && a.n <= 12) return launch_group_np<16, 12, 4>(a, s);
+        // NP also bounds the rows of Y the compact flush stores (NST pair stores cover kChunk NP doubles per output),
+        // so the narrow instantiations need r <= NP as well as n <= NP
+        if (a.m <= 4 && a.n <= 8 && a.r <= 8) return launch_group_np<16, 8, 4>(a, s);
+        if (a.m <= 4 && a.n <= 12 && a.r <= 12) return launch_group_np<16, 12, 4>(a, s);
     }
     return launch_group_np<G, G, G>(a, s);
 }

@@ -42,6 +42,22 @@ def test_rollout_shapes_per_instance_inputs(ctx, n, m, r, T, interleave):
     assert_close(got["Y"], Y, f"n{n} m{m} r{r} T{T} W={interleave} Y")
 
 
+@pytest.mark.parametrize("n,m,r", [(4, 1, 10), (8, 2, 16), (12, 4, 14), (2, 1, 12), (6, 3, 8), (10, 2, 12)])
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("interleave", [1, 0])
+def test_rollout_more_outputs_than_states(ctx, n, m, r, shared, interleave):
+    """r > n: the output rows, not the state rows, size the flush of Y (even n, r take the paired-store path at W = 1)."""
+    rng = np.random.default_rng(1000 + n * 31 + m * 7 + r)
+    batch, T = 37, 29  # T not a multiple of the 8-step chunk
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    x0 = rng.standard_normal((batch, n))
+    U = rng.standard_normal((m, T)) if shared else rng.standard_normal((batch, m, T))
+    X, Y, _ = orc.rollout_batch(A, B, C, x0, U, threads=4)
+    got = ctx.rollout(A, B, C, x0, U, interleave=interleave)
+    assert_close(got["X"], X, f"n{n} m{m} r{r} shared={shared} W={interleave} X")
+    assert_close(got["Y"], Y, f"n{n} m{m} r{r} shared={shared} W={interleave} Y")
+
+
 def test_propagate_dynamics_is_rollout_with_T1(ctx):
     rng = np.random.default_rng(5)
     A, B, C = random_stable_plants(rng, 40, 4, 1, 1)
