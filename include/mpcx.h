@@ -164,6 +164,22 @@ int mpcx_c2d_backward_euler_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const 
                                     double *A, double *B, int32_t *info, void *stream);
 
 /*
+ * mpcx_c2d_backward_euler_f64_dev for callers that cannot allocate device memory while they run: code under HIP
+ * graph capture, tight serving loops that re-discretise every tick, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference (the computation is model.rs:55-57, :138-140 as above).  Same arguments, same kernels and
+ * bit-identical results; it never calls hipMalloc / hipFree or any allocating routine.  Its only scratch, I - Ac dt of
+ * every instance, lives in a static device array of MPCX_C2D_NOALLOC_MAX_DOUBLES doubles (16 MiB on each GPU the
+ * library runs on, held until the process ends), whose address on the context's device mpcx_create resolves.
+ * Limits, reported as MPCX_ERR_UNSUPPORTED with a message: mpcx_array_elems(batch, interleave, n n) must not exceed
+ * MPCX_C2D_NOALLOC_MAX_DOUBLES (plants the one-lane kernels take -- n <= 6 with m <= 2 -- need no scratch and have no
+ * such limit), and n must be small enough for the on-chip solver (n <= 100).  All calls on one GPU share that GPU's
+ * array: two such calls that overlap in time on one device (different streams or contexts) race.
+ */
+#define MPCX_C2D_NOALLOC_MAX_DOUBLES ((int64_t)1 << 21)
+int mpcx_c2d_backward_euler_f64_noalloc_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *Ac, const double *Bc,
+                                            double dt, double *A, double *B, int32_t *info, void *stream);
+
+/*
  * The reference's two plants from per-instance physical parameters, discretised: dc_motor::Model::new
  * (model.rs:45-66; parameters b, j, k, l, r in that order; n = 2) and mpc::Model::new (model.rs:126-149; m1, m2, k1,
  * k2, d1, d2; n = 4).  m = r = 1.  `params` holds 5 resp. 6 values per instance in the batch layout; A (n x n),

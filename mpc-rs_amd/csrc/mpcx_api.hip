@@ -163,7 +163,19 @@ int mpcx_create(mpcx_ctx **out, int device_id) {
         return (int)e;
     }
     e = hipMalloc(&ctx->stat_scratch, stats_scratch_bytes() + 256);
+    if (e == hipSuccess) {  // band structure of W3, measured on the device by every build call of the workgroup kernels
+        e = hipMalloc(&ctx->w3win, 256);
+        ctx->w3win_bytes = 256;
+    }
+    if (e == hipSuccess) {
+        // the allocation-free discretisation works in a static device array: resolve its address on this device now
+        double *p = nullptr;
+        const int rc = c2d_static_scratch(device_id, &p);
+        if (rc > 0) e = (hipError_t)rc;  // a device index beyond the table only disables that entry point
+    }
     if (e != hipSuccess) {
+        if (ctx->stat_scratch) (void)hipFree(ctx->stat_scratch);
+        if (ctx->w3win) (void)hipFree(ctx->w3win);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return (int)e;
@@ -325,10 +337,6 @@ int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, co
     a.w3win = nullptr;
     a.w3win_bytes = 0;
     if (H) {  // where the workgroup kernels measure the band structure of W3
-        if (!ctx->w3win) {
-            HIP_TRY(ctx, hipMalloc(&ctx->w3win, 256));
-            ctx->w3win_bytes = 256;
-        }
         a.w3win = ctx->w3win;
         a.w3win_bytes = ctx->w3win_bytes;
     }
@@ -611,6 +619,37 @@ int mpcx_c2d_backward_euler_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const dou
         rc = ensure_lu_work(ctx, d->n, d->n, d->batch, &wsd);
         if (rc != MPCX_OK) return rc;
         rc = launch_c2d_general(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, (double *)ctx->aux, (double *)ctx->lu_work, wsd, s);
+    }
+    if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "c2d: n = %d is beyond what the solver holds on chip", d->n);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "c2d launch");
+    return MPCX_OK;
+}
+
+int mpcx_c2d_backward_euler_f64_noalloc_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *Ac, const double *Bc, double dt,
+                                            double *A, double *B, int32_t *info, void *stream) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->batch == 0) return MPCX_OK;
+    if (!Ac || !Bc || !A || !B) return fail(ctx, MPCX_ERR_NULL, "Ac, Bc, A and B are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_c2d_lane(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, s);  // tiny plants: registers only, no scratch
+    if (rc == MPCX_ERR_UNSUPPORTED) {
+        if (!solve_fits_on_chip(d->n, d->n))
+            return fail(ctx, MPCX_ERR_UNSUPPORTED, "c2d (no-allocation entry point): n = %d needs the blocked solver's device "
+                        "workspace; use mpcx_c2d_backward_euler_f64_dev", d->n);
+        const size_t need = (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n);
+        if (need > c2d_static_scratch_doubles())
+            return fail(ctx, MPCX_ERR_UNSUPPORTED, "c2d (no-allocation entry point): batch x n^2 = %zu doubles exceeds the static "
+                        "scratch of %zu doubles; split the batch or use mpcx_c2d_backward_euler_f64_dev", need,
+                        c2d_static_scratch_doubles());
+        double *tmp = nullptr;
+        rc = c2d_static_scratch(ctx->device, &tmp);
+        if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "c2d (no-allocation entry point): device index %d is beyond the table", ctx->device);
+        if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "hipGetSymbolAddress(mpcx_c2d_scratch)");
+        // every element of the scratch that the solver reads is written first by this call: nothing to clear
+        rc = launch_c2d_general(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, tmp, nullptr, 0, s);
     }
     if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "c2d: n = %d is beyond what the solver holds on chip", d->n);
     if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "c2d launch");

@@ -56,6 +56,10 @@ int launch_c2d_lane(const double *Ac, const double *Bc, double dt, double *A, do
                     int n, int m, hipStream_t s);
 int launch_c2d_general(const double *Ac, const double *Bc, double dt, double *A, double *B, int *info, long long batch,
                        long long W, int n, int m, double *tmp, double *ws, size_t ws_doubles, hipStream_t s);
+// Static device scratch of the allocation-free discretisation: capacity in doubles, and its address on the current
+// device (`device` must be current; returns 0, a hipError_t, or MPCX_ERR_UNSUPPORTED for a device index beyond the table).
+size_t c2d_static_scratch_doubles();
+int c2d_static_scratch(int device, double **ptr);
 int launch_plants(int kind, const double *params, double dt, double *A, double *B, double *C, int *info, long long batch,
                   long long W, hipStream_t s);
 bool solve_fits_on_chip(int nr, int nrhs);

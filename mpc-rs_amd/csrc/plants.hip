@@ -12,6 +12,15 @@
 //                         place in the output A) and B = A (Bc dt) follows elementwise
 #include "mpcx_internal.h"
 
+#include <mutex>
+
+// Scratch of the allocation-free discretisation (mpcx_c2d_backward_euler_f64_noalloc_dev): I - Ac dt of every instance
+// of a call, in the batch layout.  One copy per GPU, at its own address on each, held until the process ends.  The
+// name below is a host-side handle, not a device address: host code reaches the memory only through the pointer
+// hipGetSymbolAddress returns for the current device (c2d_static_scratch).
+#define MPCX_C2D_SCRATCH_DOUBLES ((size_t)1 << 21) /* 16 MiB */
+static __device__ __align__(256) double mpcx_c2d_scratch[MPCX_C2D_SCRATCH_DOUBLES];
+
 namespace mpcx {
 bool qp_lane_supports(int n, int m, int r);
 namespace {
@@ -232,6 +241,31 @@ int launch_plants(int kind, const double *params, double dt, double *A, double *
     else
         return MPCX_ERR_UNSUPPORTED;
     return (int)hipGetLastError();
+}
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+double *g_scratch_ptr[kMaxDevices];  // device address of mpcx_c2d_scratch on each GPU, resolved once per device
+}  // namespace
+
+size_t c2d_static_scratch_doubles() { return MPCX_C2D_SCRATCH_DOUBLES; }
+
+// Device address of this GPU's copy of the static scratch.  `device` must be the current device.  The first call for a
+// device resolves the symbol (which loads the code object there if needed); later calls are a table look-up.
+int c2d_static_scratch(int device, double **ptr) {
+    *ptr = nullptr;
+    if (device < 0 || device >= kMaxDevices) return MPCX_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(mpcx_c2d_scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return (int)hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = (double *)p;
+    }
+    *ptr = g_scratch_ptr[device];
+    return 0;
 }
 
 }  // namespace mpcx

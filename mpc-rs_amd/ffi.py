@@ -29,7 +29,8 @@ EXPORTS = (
     "mpcx_qp_build_f64", "mpcx_qp_build_f64_dev", "mpcx_rollout_f64", "mpcx_rollout_f64_dev",
     "mpcx_qp_solve_f64", "mpcx_qp_solve_f64_dev", "mpcx_qp_gain_f64", "mpcx_qp_gain_f64_dev",
     "mpcx_closed_loop_f64", "mpcx_closed_loop_f64_dev",
-    "mpcx_c2d_backward_euler_f64", "mpcx_c2d_backward_euler_f64_dev", "mpcx_plants_f64", "mpcx_plants_f64_dev",
+    "mpcx_c2d_backward_euler_f64", "mpcx_c2d_backward_euler_f64_dev", "mpcx_c2d_backward_euler_f64_noalloc_dev",
+    "mpcx_plants_f64", "mpcx_plants_f64_dev",
     "mpcx_stats_f64_dev", "mpcx_stats_f64", "mpcx_relayout_f64_dev",
 )
 
@@ -105,6 +106,8 @@ def lib() -> C.CDLL:
     lb.mpcx_c2d_backward_euler_f64.restype = C.c_int
     lb.mpcx_c2d_backward_euler_f64_dev.argtypes = [vp, C.POINTER(Dims), dp, dp, C.c_double, dp, dp, vp, vp]
     lb.mpcx_c2d_backward_euler_f64_dev.restype = C.c_int
+    lb.mpcx_c2d_backward_euler_f64_noalloc_dev.argtypes = [vp, C.POINTER(Dims), dp, dp, C.c_double, dp, dp, vp, vp]
+    lb.mpcx_c2d_backward_euler_f64_noalloc_dev.restype = C.c_int
     lb.mpcx_plants_f64.argtypes = [vp, C.c_int, i64, i64, dp, C.c_double, dp, dp, dp, vp]
     lb.mpcx_plants_f64.restype = C.c_int
     lb.mpcx_plants_f64_dev.argtypes = [vp, C.c_int, i64, i64, dp, C.c_double, dp, dp, dp, vp, vp]
@@ -245,6 +248,10 @@ class Context:
 
     def plants_dev(self, kind, batch, interleave, params, dt, A, B, Cm, info, stream=0):
         self._check(self._lib.mpcx_plants_f64_dev(self._h, kind, batch, interleave, params, dt, A, B, Cm, info, stream))
+
+    def c2d_noalloc_dev(self, dims: Dims, Ac, Bc, dt, A, B, info, stream=0):
+        """Same as c2d_dev, through the entry point that allocates no device memory (static device scratch)."""
+        self._check(self._lib.mpcx_c2d_backward_euler_f64_noalloc_dev(self._h, C.byref(dims), Ac, Bc, dt, A, B, info, stream))
 
     def c2d(self, Ac, Bc, dt, interleave=L.INTERLEAVE_AOS):
         """Ac (batch, n, n), Bc (batch, n, m) -> A, B, info: backward Euler, A = (I - Ac dt)^-1, B = A Bc dt."""

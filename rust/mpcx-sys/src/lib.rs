@@ -94,6 +94,9 @@ extern "C" {
         dt: f64, a: *mut f64, b: *mut f64, info: *mut i32) -> c_int;
     pub fn mpcx_c2d_backward_euler_f64_dev(ctx: *mut mpcx_ctx, dims: *const mpcx_dims, ac: *const f64,
         bc: *const f64, dt: f64, a: *mut f64, b: *mut f64, info: *mut i32, stream: *mut c_void) -> c_int;
+    /// Same as `mpcx_c2d_backward_euler_f64_dev` without any device allocation (static device scratch, bounded batch).
+    pub fn mpcx_c2d_backward_euler_f64_noalloc_dev(ctx: *mut mpcx_ctx, dims: *const mpcx_dims, ac: *const f64,
+        bc: *const f64, dt: f64, a: *mut f64, b: *mut f64, info: *mut i32, stream: *mut c_void) -> c_int;
     pub fn mpcx_plants_f64(ctx: *mut mpcx_ctx, kind: c_int, batch: i64, interleave: i64, params: *const f64, dt: f64,
         a: *mut f64, b: *mut f64, c: *mut f64, info: *mut i32) -> c_int;
     pub fn mpcx_plants_f64_dev(ctx: *mut mpcx_ctx, kind: c_int, batch: i64, interleave: i64, params: *const f64,
