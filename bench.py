@@ -12,6 +12,12 @@ are sharded by index across ranks (one process per GPU, no collective on the dat
 per-GPU batch is fixed); after the timed region the ranks all-gather one fixed-size statistics record each over
 RCCL.  Rank 0 prints ONE JSON line.
 
+`--gpus N` with N > 1 and no torchrun environment (WORLD_SIZE unset) starts N ranks itself: the parent, before it
+imports torch or touches HIP, launches N fresh child processes of this script (RANK = LOCAL_RANK = 0..N-1, rendezvous on
+127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank does.  Under torchrun the world size must equal
+--gpus.  At N = 1 with the default workload the line also carries, under "also", the other configurations (msd,
+quadrotor, long-horizon builds incl. held inputs f > v, and rollouts), each timed the same way on a few steps.
+
 The default workload is the one the headline metric is quoted on: the reference's two-mass plant (n=4, m=1, r=1,
 f=v=20) perturbed per instance, 1,048,576 instances per GPU (8,388,608 over 8 GPUs).
 """
@@ -75,7 +81,17 @@ def main():
                     help="N > 1: result array gathered to rank 0 over RCCL after the timed region (reported apart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances timed on the CPU (default: ~15 s worth)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under \"also\"")
+    ap.add_argument("--also-steps", type=int, default=5)
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher above us: become one.  Nothing in this process has initialised the GPU (torch is not even
+        # imported yet); the ranks are fresh child processes.
+        from mpc_rs_amd import launch
+        sys.exit(launch.run_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -85,129 +101,159 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
     # Rehearsal knob (not used by the driver): MPCX_BENCH_REHEARSE=1 runs all ranks on device 0 over gloo, so the
     # N > 1 code path can be exercised on a one-GPU box.  The real run is one rank per GPU over RCCL ("nccl").
     rehearse = os.environ.get("MPCX_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    backend = None
+    if not rehearse and torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     if world > 1:
+        backend = "gloo" if rehearse else "nccl"  # "nccl" is RCCL on ROCm
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = ffi.Context(local_rank)
 
-    wl = synth.WORKLOADS[args.workload]
-    n, m, r, f, v, T = wl["n"], wl["m"], wl["r"], wl["f"], wl["v"], wl["T"]
-    if args.f:
-        f = args.f
-        v = args.v or f
-    per_gpu = args.batch or DEFAULT_BATCH[args.workload]
-    lane_native = (m <= 2 and r <= 2 and n <= 6)
-    # lane kernels: batch tiled in groups of 4096 instances (measured fastest); workgroup kernels: instance-major
-    il = args.interleave if args.interleave >= 0 else (4096 if lane_native else L.INTERLEAVE_AOS)
-    start, count = shard.shard_range(per_gpu * world, world, rank)
-    assert count == per_gpu
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
 
-    # ---- synthetic shard, generated in chunks on the host and made resident in HBM ----
     def to_dev(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
-    d = synth.make_batch(args.workload, count, start=start, f=f, v=v)
-    bufs = {k: to_dev(L.pack(d[k], il)) for k in ("A", "B", "C")}
-    bufs["x0"] = to_dev(L.pack(d["x0"].reshape(count, n, 1), il))
-    bufs["ref"] = to_dev(L.pack(d["ref"].reshape(count, f * r, 1), il))
-    bufs["W3"] = to_dev(L.colmajor(d["W3"]))
-    bufs["Q"] = to_dev(L.colmajor(d["Q"]))
-    bufs["U"] = to_dev(L.colmajor(d["U"]))
+    def make_case(workload, op, batch=0, interleave=-1, f_over=0, v_over=0, hessian=0):
+        """Synthetic shard of `workload` resident in HBM plus the closure that runs one step of `op` on it."""
+        from types import SimpleNamespace
+        wl = synth.WORKLOADS[workload]
+        n, m, r, f, v, T = wl["n"], wl["m"], wl["r"], wl["f"], wl["v"], wl["T"]
+        if f_over:
+            f = f_over
+            v = v_over or f
+        per_gpu = batch or DEFAULT_BATCH[workload]
+        lane_native = (m <= 2 and r <= 2 and n <= 6)
+        # lane kernels: batch tiled in groups of 4096 instances (measured fastest); workgroup kernels: instance-major
+        il = interleave if interleave >= 0 else (4096 if lane_native else L.INTERLEAVE_AOS)
+        start, count = shard.shard_range(per_gpu * world, world, rank)
+        assert count == per_gpu
+        d = synth.make_batch(workload, count, start=start, f=f, v=v)
+        bufs = {k: to_dev(L.pack(d[k], il)) for k in ("A", "B", "C")}
+        bufs["x0"] = to_dev(L.pack(d["x0"].reshape(count, n, 1), il))
+        bufs["ref"] = to_dev(L.pack(d["ref"].reshape(count, f * r, 1), il))
+        bufs["W3"] = to_dev(L.colmajor(d["W3"]))
+        bufs["Q"] = to_dev(L.colmajor(d["Q"]))
+        bufs["U"] = to_dev(L.colmajor(d["U"]))
 
-    def out(elems):
-        return torch.empty(L.array_elems(count, il, elems), dtype=torch.float64, device=dev)
+        def out(elems):
+            return torch.empty(L.array_elems(count, il, elems), dtype=torch.float64, device=dev)
 
-    stream = torch.cuda.current_stream()
-    sp = stream.cuda_stream
-    if args.op == "qp":
-        outs = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
-        dims = ffi.make_dims(n, m, r, f, v, count, 0, il, ffi.WEIGHTS_BLOCK, args.hessian)
-
-        def step():
-            ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(),
-                             bufs["W3"].data_ptr(), bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(),
-                             outs["Phi"].data_ptr(), outs["Gamma"].data_ptr(), outs["H"].data_ptr(),
-                             outs["fvec"].data_ptr(), sp)
-        unit_bytes = bytes_qp(n, m, r, f, v)
-        metric, unit = "batched MPC QP builds/sec (Phi,Gamma,H,f)", "builds/s"
-        check_buf = outs["H"]
-    elif args.op == "plants":
-        # Model::new for every instance: physical parameters -> discretised A, B, C (two-mass plant, n = 4)
-        assert args.workload == "two_mass", "--op plants is the two-mass parameter sweep"
-        rng = np.random.default_rng(1234 + rank)
-        prm = np.array([2.0, 2.0, 100.0, 200.0, 1.0, 5.0]) * (1.0 + 0.1 * rng.uniform(-1, 1, (count, 6)))
-        bufs["prm"] = to_dev(L.pack(prm.reshape(count, 6, 1), il))
-        outs = {"A": out(16), "B": out(4), "C": out(4)}
-        info = torch.zeros(count, dtype=torch.int32, device=dev)
-
-        def step():
-            ctx.plants_dev(ffi.PLANT_TWO_MASS, count, il, bufs["prm"].data_ptr(), 0.05, outs["A"].data_ptr(),
-                           outs["B"].data_ptr(), outs["C"].data_ptr(), info.data_ptr(), sp)
-        unit_bytes = 8 * (6 + 16 + 4 + 4) + 4
-        metric, unit = "batched plant constructions/sec (parameters -> A,B,C)", "plants/s"
-        check_buf = outs["A"]
-    elif args.op in ("solve", "gain", "loop"):
-        # operands come from a device-side build (and gain solve) outside the timed region
-        qp = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
-        dims = ffi.make_dims(n, m, r, f, v, count, T, il, u_shared=1)
-        ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["W3"].data_ptr(),
-                         bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(), qp["Phi"].data_ptr(),
-                         qp["Gamma"].data_ptr(), qp["H"].data_ptr(), qp["fvec"].data_ptr(), sp)
-        info = torch.zeros(count, dtype=torch.int32, device=dev)
-        if args.op == "solve":
-            outs = {"u_seq": out(v * m)}
+        info = None
+        if op == "qp":
+            outs = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
+            dims = ffi.make_dims(n, m, r, f, v, count, 0, il, ffi.WEIGHTS_BLOCK, hessian)
 
             def step():
-                ctx.qp_solve_dev(dims, qp["H"].data_ptr(), qp["fvec"].data_ptr(), outs["u_seq"].data_ptr(), info.data_ptr(), sp)
-            unit_bytes = bytes_solve(m, v)
-            metric, unit = "batched condensed-QP solves/sec (u = -H^-1 f)", "solves/s"
-            check_buf = outs["u_seq"]
-        else:
-            outs = {"gain": out(v * m * f * r)}
+                ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(),
+                                 bufs["W3"].data_ptr(), bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(),
+                                 outs["Phi"].data_ptr(), outs["Gamma"].data_ptr(), outs["H"].data_ptr(),
+                                 outs["fvec"].data_ptr(), sp)
+            unit_bytes = bytes_qp(n, m, r, f, v)
+            metric, unit = "batched MPC QP builds/sec (Phi,Gamma,H,f)", "builds/s"
+            check_buf = outs["H"]
+        elif op == "plants":
+            # Model::new for every instance: physical parameters -> discretised A, B, C (two-mass plant, n = 4)
+            assert workload == "two_mass", "--op plants is the two-mass parameter sweep"
+            rng = np.random.default_rng(1234 + rank)
+            prm = np.array([2.0, 2.0, 100.0, 200.0, 1.0, 5.0]) * (1.0 + 0.1 * rng.uniform(-1, 1, (count, 6)))
+            bufs["prm"] = to_dev(L.pack(prm.reshape(count, 6, 1), il))
+            outs = {"A": out(16), "B": out(4), "C": out(4)}
+            info = torch.zeros(count, dtype=torch.int32, device=dev)
+            dims = None
 
-            def gain_step():
-                ctx.qp_gain_dev(dims, qp["H"].data_ptr(), qp["Gamma"].data_ptr(), bufs["Q"].data_ptr(),
-                                outs["gain"].data_ptr(), info.data_ptr(), sp)
-            if args.op == "gain":
-                step = gain_step
-                unit_bytes = bytes_gain(m, r, f, v)
-                metric, unit = "batched MPC gain matrices/sec (H^-1 Gamma^T W4)", "gains/s"
-                check_buf = outs["gain"]
-            else:
-                gain_step()
-                pulse = np.zeros((r, T + f))
-                pulse[:, : (T + f) // 3] = 1.0
-                pulse[:, 2 * (T + f) // 3:] = 1.0          # the shape of trajectory.rs:4-8
-                bufs["traj"] = to_dev(L.colmajor(pulse))
-                outs.update({"X": out(n * (T + 1)), "U": out(m * T), "Y": out(r * T)})
+            def step():
+                ctx.plants_dev(ffi.PLANT_TWO_MASS, count, il, bufs["prm"].data_ptr(), 0.05, outs["A"].data_ptr(),
+                               outs["B"].data_ptr(), outs["C"].data_ptr(), info.data_ptr(), sp)
+            unit_bytes = 8 * (6 + 16 + 4 + 4) + 4
+            metric, unit = "batched plant constructions/sec (parameters -> A,B,C)", "plants/s"
+            check_buf = outs["A"]
+        elif op in ("solve", "gain", "loop"):
+            # operands come from a device-side build (and gain solve) outside the timed region
+            qp = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
+            dims = ffi.make_dims(n, m, r, f, v, count, T, il, u_shared=1)
+            ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["W3"].data_ptr(),
+                             bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(), qp["Phi"].data_ptr(),
+                             qp["Gamma"].data_ptr(), qp["H"].data_ptr(), qp["fvec"].data_ptr(), sp)
+            info = torch.zeros(count, dtype=torch.int32, device=dev)
+            if op == "solve":
+                outs = {"u_seq": out(v * m)}
 
                 def step():
-                    ctx.closed_loop_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(),
-                                        bufs["x0"].data_ptr(), qp["Phi"].data_ptr(), outs["gain"].data_ptr(),
-                                        bufs["traj"].data_ptr(), outs["X"].data_ptr(), outs["U"].data_ptr(),
-                                        outs["Y"].data_ptr(), sp)
-                unit_bytes = bytes_loop(n, m, r, f, T)
-                metric, unit = "batched MPC closed-loop trajectories/sec (X,U,Y)", "trajectories/s"
-                check_buf = outs["X"]
-    else:
-        outs = {"X": out(n * (T + 1)), "Y": out(r * T)}
-        dims = ffi.make_dims(n, m, r, 1, 1, count, T, il, u_shared=1)
+                    ctx.qp_solve_dev(dims, qp["H"].data_ptr(), qp["fvec"].data_ptr(), outs["u_seq"].data_ptr(), info.data_ptr(), sp)
+                unit_bytes = bytes_solve(m, v)
+                metric, unit = "batched condensed-QP solves/sec (u = -H^-1 f)", "solves/s"
+                check_buf = outs["u_seq"]
+            else:
+                outs = {"gain": out(v * m * f * r)}
 
-        def step():
-            ctx.rollout_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["x0"].data_ptr(),
-                            bufs["U"].data_ptr(), outs["X"].data_ptr(), outs["Y"].data_ptr(), sp)
-        unit_bytes = bytes_rollout(n, m, r, T) - 8 * m * T  # the shared input is read once, not per instance
-        metric, unit = "batched state-space rollout trajectories/sec (X,Y)", "trajectories/s"
-        check_buf = outs["X"]
+                def gain_step():
+                    ctx.qp_gain_dev(dims, qp["H"].data_ptr(), qp["Gamma"].data_ptr(), bufs["Q"].data_ptr(),
+                                    outs["gain"].data_ptr(), info.data_ptr(), sp)
+                if op == "gain":
+                    step = gain_step
+                    unit_bytes = bytes_gain(m, r, f, v)
+                    metric, unit = "batched MPC gain matrices/sec (H^-1 Gamma^T W4)", "gains/s"
+                    check_buf = outs["gain"]
+                else:
+                    gain_step()
+                    pulse = np.zeros((r, T + f))
+                    pulse[:, : (T + f) // 3] = 1.0
+                    pulse[:, 2 * (T + f) // 3:] = 1.0          # the shape of trajectory.rs:4-8
+                    bufs["traj"] = to_dev(L.colmajor(pulse))
+                    outs.update({"X": out(n * (T + 1)), "U": out(m * T), "Y": out(r * T)})
+
+                    def step():
+                        ctx.closed_loop_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(),
+                                            bufs["x0"].data_ptr(), qp["Phi"].data_ptr(), outs["gain"].data_ptr(),
+                                            bufs["traj"].data_ptr(), outs["X"].data_ptr(), outs["U"].data_ptr(),
+                                            outs["Y"].data_ptr(), sp)
+                    unit_bytes = bytes_loop(n, m, r, f, T)
+                    metric, unit = "batched MPC closed-loop trajectories/sec (X,U,Y)", "trajectories/s"
+                    check_buf = outs["X"]
+            outs["_operands"] = qp
+        else:
+            outs = {"X": out(n * (T + 1)), "Y": out(r * T)}
+            dims = ffi.make_dims(n, m, r, 1, 1, count, T, il, u_shared=1)
+
+            def step():
+                ctx.rollout_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["x0"].data_ptr(),
+                                bufs["U"].data_ptr(), outs["X"].data_ptr(), outs["Y"].data_ptr(), sp)
+            unit_bytes = bytes_rollout(n, m, r, T) - 8 * m * T  # the shared input is read once, not per instance
+            metric, unit = "batched state-space rollout trajectories/sec (X,Y)", "trajectories/s"
+            check_buf = outs["X"]
+        name = f"{workload}: n={n} m={m} r={r} " + (f"f=v={f}" if f == v else f"f={f} v={v}") + (f" T={T}" if op in ("rollout", "loop") else "")
+        return SimpleNamespace(workload=workload, op=op, name=name, n=n, m=m, r=r, f=f, v=v, T=T, il=il, per_gpu=per_gpu,
+                               count=count, d=d, bufs=bufs, outs=outs, dims=dims, step=step, unit_bytes=unit_bytes,
+                               metric=metric, unit=unit, check_buf=check_buf, info=info, hessian=hessian)
+
+    def event_ms(fn, steps):
+        """Mean duration of fn() over `steps` calls, HIP events on the launch stream around each call."""
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in ev:
+            a.record(stream)
+            fn()
+            b.record(stream)
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    case = make_case(args.workload, args.op, args.batch, args.interleave, args.f, args.v, args.hessian)
+    n, m, r, f, v, T, il, per_gpu, count = case.n, case.m, case.r, case.f, case.v, case.T, case.il, case.per_gpu, case.count
+    step, outs, unit_bytes, check_buf, bufs, dims = case.step, case.outs, case.unit_bytes, case.check_buf, case.bufs, case.dims
 
     def barrier():
         torch.cuda.synchronize()
@@ -237,13 +283,7 @@ def main():
                              None, sp)
         h_only()
         torch.cuda.synchronize()
-        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        for a, b in ev2:
-            a.record(stream)
-            h_only()
-            b.record(stream)
-        torch.cuda.synchronize()
-        mfma_ms = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
+        mfma_ms = event_ms(h_only, args.steps)
 
     # ---- statistics record of this shard; ranks exchange records (RCCL), never results ----
     rec = torch.zeros(6, dtype=torch.int64, device=dev)
@@ -287,14 +327,16 @@ def main():
         value = total * args.steps / elapsed
         achieved = unit_bytes * per_gpu / (kernel_ms * 1e-3)
         res = {
-            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+            "metric": case.metric, "value": value, "unit": case.unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: n={n} m={m} r={r} " + (f"f=v={f}" if f == v else f"f={f} v={v}") + (f" T={T}" if args.op in ("rollout", "loop") else ""),
+            "config": {"workload": case.name,
                        "op": args.op, "batch_per_gpu": per_gpu, "global_batch": total, "interleave": il,
-                       "parallelism": f"batch-sharded x{world}", "hessian_algo": args.hessian},
+                       "parallelism": f"batch-sharded x{world}", "hessian_algo": args.hessian,
+                       "world_size": world, "backend": backend},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": _traffic(args, per_gpu),
+                         "frac": achieved / HBM_PEAK, "traffic": _traffic(args.op, args.workload, per_gpu, f, v),
+                         "traffic_source": "profiles/traffic.json: rocprofv3 --pmc passes of this command, recorded per launch",
                          "kernel_ms": kernel_ms, "bytes_per_unit": unit_bytes},
             "check": {"elements": merged["count"], "non_finite": merged["non_finite"], "sum_sq": merged["sum_sq"],
                       "checksum": "%016x" % merged["checksum"]},
@@ -302,31 +344,85 @@ def main():
         if gathered is not None:
             res["gather"] = gathered
         if mfma_ms is not None:
-            # the contraction kernel against the FP64 matrix-core peak, in algorithmic flops (symmetric count,
-            # block-diagonal weight); the dense count 2 (f r)(v m)^2 is printed beside it
-            fl = flops_h(m, r, f, v) * per_gpu / (mfma_ms * 1e-3)
-            res["roofline"] = {"bound": "mfma", "achieved": fl / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
-                               "frac": fl / FP64_PEAK, "traffic": None, "kernel_ms": mfma_ms,
-                               "kernel": "hessian_mfma_kernel", "flops_per_unit": flops_h(m, r, f, v),
+            # The contraction kernel against the FP64 matrix-core peak.  `frac` counts the flops the kernel EXECUTES:
+            # one v_mfma_f64_16x16x4_f64 is 2048 flops and the kernel issues a fixed number of them per instance
+            # (mfma_insts_per_unit, confirmed by the SQ_INSTS_VALU_MFMA_F64 counter pass recorded under profiles/).
+            # The algorithmic rate (symmetric count, block-diagonal weight) is a side field: it exceeds what ran only
+            # on paper, because the dense contraction also multiplies structural zeros.
+            insts = _mfma_insts(args.workload, per_gpu, f, v)
+            fl_alg = flops_h(m, r, f, v) * per_gpu / (mfma_ms * 1e-3)
+            fl_exec = (insts * 2048.0 / (mfma_ms * 1e-3)) if insts else None
+            res["roofline"] = {"bound": "mfma", "achieved": (fl_exec or 0.0) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
+                               "frac": (fl_exec / FP64_PEAK) if fl_exec else None, "traffic": None, "kernel_ms": mfma_ms,
+                               "kernel": "hessian_mfma_kernel", "mfma_insts_per_launch": insts,
+                               "algorithmic_TFLOP_per_s": fl_alg / 1e12, "algorithmic_frac": fl_alg / FP64_PEAK,
+                               "flops_per_unit": flops_h(m, r, f, v),
                                "dense_flops_per_unit": 2 * f * r * (v * m) ** 2, "step_ms_all_kernels": kernel_ms,
                                "hbm_frac_whole_step": achieved / HBM_PEAK}
         if args.op in ("solve", "gain", "loop", "plants"):
-            res["check"]["singular_instances"] = int((info != 0).sum().item())
+            res["check"]["singular_instances"] = int((case.info != 0).sum().item())
         if world == 1 and not args.no_cpu_baseline and args.op in ("qp", "rollout"):
-            res["cpu_baseline"] = _cpu_baseline(args, d, n, m, r, f, v, T, unit, outs, il, count)
+            res["cpu_baseline"] = _cpu_baseline(args, case.d, n, m, r, f, v, T, case.unit, outs, il, count)
+
+    # ---- the other configurations, N = 1 and the default command only: same timing, a few steps each ----
+    if world == 1 and not args.no_also and args.workload == "two_mass" and args.op == "qp" and not (args.f or args.batch or args.hessian):
+        del case, outs, bufs, check_buf
+        torch.cuda.empty_cache()
+        also = []
+        t_also = time.perf_counter()
+        for wl_name, op, fo, vo in ALSO:
+            if time.perf_counter() - t_also > 60.0:  # never let the extras dominate the run
+                also.append({"workload": wl_name, "op": op, "skipped": "time budget"})
+                continue
+            try:
+                c = make_case(wl_name, op, f_over=fo, v_over=vo)
+                c.step()
+                c.step()
+                torch.cuda.synchronize()
+                ms = event_ms(c.step, args.also_steps)
+                ach = c.unit_bytes * c.per_gpu / (ms * 1e-3)
+                also.append({"workload": c.name, "op": op, "batch": c.per_gpu, "interleave": c.il, "steps": args.also_steps,
+                             "ms_per_step": ms, "value": c.per_gpu / (ms * 1e-3), "unit": c.unit,
+                             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                          "frac": ach / HBM_PEAK, "traffic": _traffic(op, wl_name, c.per_gpu, c.f, c.v),
+                                          "bytes_per_unit": c.unit_bytes}})
+                del c
+                torch.cuda.empty_cache()
+            except Exception as exc:  # an extra must never cost the headline line
+                also.append({"workload": wl_name, "op": op, "error": str(exc)[:200]})
+        res["also"] = also
+    if rank == 0:
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def _traffic(args, per_gpu):
+# extra configurations of the default run: (workload, op, f override, v override)
+ALSO = (("msd", "qp", 0, 0), ("quadrotor", "qp", 0, 0), ("long", "qp", 0, 0),
+        ("quadrotor", "qp", 50, 25), ("long", "qp", 400, 200),
+        ("msd", "rollout", 0, 0), ("two_mass", "rollout", 0, 0), ("quadrotor", "rollout", 0, 0))
+
+
+def _mfma_insts(workload, per_gpu, f, v):
+    """v_mfma_f64_16x16x4_f64 instructions one launch of the contraction kernel issues, from the counter pass recorded
+    under profiles/ (SQ_INSTS_VALU_MFMA_F64; the count is a function of the shape only)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh).get(f"mfma:{workload}:{per_gpu}:{f}:{v}")
+        return rec["mfma_insts_per_launch"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _traffic(op, workload, per_gpu, f=0, v=0):
     """HBM bytes per launch from the PMC passes recorded under profiles/ (null when no matching record)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
             table = json.load(fh)
-        rec = table.get(f"{args.op}:{args.workload}:{per_gpu}")
+        rec = table.get(f"{op}:{workload}:{per_gpu}:{f}:{v}") or (table.get(f"{op}:{workload}:{per_gpu}") if f == v else None)
         return rec["hbm_bytes_per_launch"] if rec else None
     except (OSError, ValueError, KeyError):
         return None
