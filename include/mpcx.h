@@ -15,7 +15,9 @@
  *     One process per GPU is the intended deployment; batches are sharded by instance index across processes.
  *   - Host-pointer calls (no suffix) copy inputs to the device, run, copy the outputs back and return when the
  *     outputs are in place.  `_dev` calls take device pointers and a hipStream_t (as void*), enqueue the work
- *     and return without synchronising.  Callers own every buffer; the library keeps no pointer after return.
+ *     and return without synchronising -- except that a call which has to grow the context's device scratch
+ *     allocates, which synchronises the device (see mpcx_reserve).  Callers own every buffer; the library keeps
+ *     no pointer after return.
  *   - Matrices of one instance are column-major, as nalgebra's DMatrix::as_slice() yields them: element (i, j)
  *     of a rows x cols matrix has element index e = j*rows + i.
  *   - Batch layout (`interleave`, W): element e of instance b of an array with E elements per instance lives at
@@ -94,6 +96,23 @@ void mpcx_destroy(mpcx_ctx *ctx);
 const char *mpcx_last_error(const mpcx_ctx *ctx);
 
 /*
+ * Device scratch.  Besides the caller's arrays some calls work in device scratch that the context owns and grows on
+ * demand: the blocked solver's workspace (solve / gain / c2d beyond what fits on chip), I - Ac dt of the general
+ * discretisation, the instance-major copy of an interleaved batch on the workgroup kernels, and the host-pointer
+ * calls' staging.  Growing a buffer is hipFree + hipMalloc, which synchronise the device: the FIRST `_dev` call of a
+ * given size therefore may block, later ones only enqueue.  mpcx_reserve grows every buffer that the `_dev` calls of
+ * `dims` (build, solve, gain, c2d; its batch, interleave, n, m, r, f, v, weights_mode, hessian_algo) would need, so that
+ * after it those calls never allocate.  All calls of a context share its scratch: run one call per context at a time
+ * (build, solve, gain and c2d alike), or use one context per stream.
+ */
+int mpcx_reserve(mpcx_ctx *ctx, const mpcx_dims *dims);
+
+/* Context options.  MPCX_OPT_RELAY_CAP_BYTES: upper bound of the instance-major copy through which an interleaved batch
+ * reaches the workgroup kernels (default 2 GiB; the batch goes through in chunks of that size). */
+#define MPCX_OPT_RELAY_CAP_BYTES 1
+int mpcx_set_option(mpcx_ctx *ctx, int option, int64_t value);
+
+/*
  * Condensed QP construction, batched.  Replaces Controller::form_lifted_matrices up to the Hessian
  * (controller.rs:16-93) and the `O x - ref` / `M^T W4` pieces of compute_control_input and of the gain
  * (controller.rs:125-127, :96), for `batch` independent plants:
@@ -133,7 +152,12 @@ int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, 
                          const double *x0, const double *U, double *X, double *Y, void *stream);
 
 /*
- * Batched solve with the condensed Hessian (LU with partial pivoting per instance, as nalgebra's try_inverse).
+ * Batched solve with the condensed Hessian: Gaussian elimination with partial pivoting per instance.  nalgebra's
+ * try_inverse does the same for dimensions above 4 and takes closed-form (cofactor) inverses for 1..4, which fail on
+ * `determinant == 0.0` (controller.rs:93-95, model.rs:56); the device always pivots.  For v m <= 4 (and n <= 4 in the
+ * discretisation) the two therefore agree on exactly singular matrices built from exact zeros, may flag different
+ * instances among matrices that are singular only to rounding, and round differently on the rest (within the 1e-10
+ * bar scaled by the condition number).
  *   mpcx_qp_solve:  u_seq (v m per instance) = -H^-1 fvec: the optimal input sequence; its first m entries are the
  *                   move the reference applies (controller.rs:130-134 with gain s = -H^-1 fvec).
  *   mpcx_qp_gain:   gain ((v m) x (f r) per instance) = H^-1 Gamma^T W4, the reference's gain_matrix

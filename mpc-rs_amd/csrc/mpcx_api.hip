@@ -23,6 +23,7 @@ struct mpcx_ctx {
     size_t relay_bytes;
     void *w3win;         // band structure of W3, measured on the device by every build call of the workgroup kernels
     size_t w3win_bytes;
+    size_t relay_cap;    // MPCX_OPT_RELAY_CAP_BYTES
     char err[512];
 };
 
@@ -156,6 +157,7 @@ int mpcx_create(mpcx_ctx **out, int device_id) {
     ctx->w3win_bytes = 0;
     ctx->relay = nullptr;
     ctx->relay_bytes = 0;
+    ctx->relay_cap = (size_t)2 << 30;
     ctx->err[0] = 0;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -200,6 +202,16 @@ void mpcx_destroy(mpcx_ctx *ctx) {
 
 const char *mpcx_last_error(const mpcx_ctx *ctx) { return ctx ? ctx->err : "context is NULL"; }
 
+int mpcx_set_option(mpcx_ctx *ctx, int option, int64_t value) {
+    if (!ctx) return MPCX_ERR_NULL;
+    if (option == MPCX_OPT_RELAY_CAP_BYTES) {
+        if (value < 1) return fail(ctx, MPCX_ERR_DIMS, "MPCX_OPT_RELAY_CAP_BYTES must be >= 1");
+        ctx->relay_cap = (size_t)value;
+        return MPCX_OK;
+    }
+    return fail(ctx, MPCX_ERR_DIMS, "unknown option %d", option);
+}
+
 // Kernel-family dispatch of one build on prepared arguments.  The dense-weight kernel, the matrix-core contraction and
 // the workgroup kernels take instance-major data (a.W == 1); the caller re-lays interleaved batches out for them.
 static int qp_build_core(mpcx_ctx *ctx, const mpcx_dims *d, QpArgs a, hipStream_t s) {
@@ -238,9 +250,28 @@ static int qp_build_core(mpcx_ctx *ctx, const mpcx_dims *d, QpArgs a, hipStream_
 }
 
 // Interleaved batch on kernels that take instance-major data: the batch goes through an instance-major copy in chunks
-// of at most kRelayCap bytes (inputs re-laid out into the context's scratch, built there, outputs re-laid out into the
+// of at most ctx->relay_cap bytes (inputs re-laid out into the context's scratch, built there, outputs re-laid out into the
 // caller's arrays).  A compatibility path: it moves every output three times.
-constexpr size_t kRelayCap = (size_t)2 << 30;
+static int ensure_relay(mpcx_ctx *ctx, size_t want) {
+    if (want <= ctx->relay_bytes) return MPCX_OK;
+    if (ctx->relay) {
+        HIP_TRY(ctx, hipFree(ctx->relay));
+        ctx->relay = nullptr;
+        ctx->relay_bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->relay, want));
+    ctx->relay_bytes = want;
+    return MPCX_OK;
+}
+
+// instances per chunk of the instance-major copy: what the cap holds, in whole groups of 64, at least one
+static long long relay_chunk(const mpcx_ctx *ctx, long long per_instance_doubles, long long batch) {
+    long long cnt = (long long)(ctx->relay_cap / ((size_t)per_instance_doubles * sizeof(double)));
+    if (cnt < 1) cnt = 1;
+    if (cnt >= 64) cnt &= ~63LL;
+    return cnt > batch ? batch : cnt;
+}
+
 static int qp_build_relayed(mpcx_ctx *ctx, const mpcx_dims *d, const QpArgs &a, hipStream_t s) {
     const long long n = a.n, m = a.m, r = a.r, FR = (long long)a.f * a.r, VM = (long long)a.v * a.m;
     const double *in[5] = {a.A, a.B, a.C, a.fvec ? a.x0 : nullptr, a.fvec ? a.ref : nullptr};
@@ -250,24 +281,10 @@ static int qp_build_relayed(mpcx_ctx *ctx, const mpcx_dims *d, const QpArgs &a, 
     long long per = 0;
     for (int i = 0; i < 5; ++i) per += in[i] ? in_e[i] : 0;
     for (int i = 0; i < 4; ++i) per += out[i] ? out_e[i] : 0;
-    size_t cap = kRelayCap;
-    if (const char *env = getenv("MPCX_RELAY_CAP_BYTES")) {  // test knob: a small cap exercises the chunking
-        const long long v = atoll(env);
-        if (v > 0) cap = (size_t)v;
-    }
-    long long cnt = (long long)(cap / ((size_t)per * sizeof(double)));
-    if (cnt < 1) cnt = 1;
-    if (cnt >= 64) cnt &= ~63LL;
-    if (cnt > a.batch) cnt = a.batch;
-    const size_t want = (size_t)cnt * (size_t)per * sizeof(double);
-    if (want > ctx->relay_bytes) {
-        if (ctx->relay) {
-            HIP_TRY(ctx, hipFree(ctx->relay));
-            ctx->relay = nullptr;
-            ctx->relay_bytes = 0;
-        }
-        HIP_TRY(ctx, hipMalloc(&ctx->relay, want));
-        ctx->relay_bytes = want;
+    const long long cnt = relay_chunk(ctx, per, a.batch);
+    {
+        const int rc = ensure_relay(ctx, (size_t)cnt * (size_t)per * sizeof(double));
+        if (rc != MPCX_OK) return rc;
     }
     for (long long c0 = 0; c0 < a.batch; c0 += cnt) {
         const long long cc = a.batch - c0 < cnt ? a.batch - c0 : cnt;
@@ -301,6 +318,37 @@ static int qp_build_relayed(mpcx_ctx *ctx, const mpcx_dims *d, const QpArgs &a, 
                             out_e[i]);
             if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "relayout launch");
         }
+    }
+    return MPCX_OK;
+}
+
+int mpcx_reserve(mpcx_ctx *ctx, const mpcx_dims *d) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->f < 1 || d->v < 1 || d->v > d->f)
+        return fail(ctx, MPCX_ERR_DIMS, "need f >= 1 and 1 <= v <= f (got f=%d, v=%d)", d->f, d->v);
+    if (d->batch == 0) return MPCX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t wsd = 0;
+    // blocked solver: solve (one right-hand side), gain (f r of them), general discretisation (n x n)
+    if ((rc = ensure_lu_work(ctx, d->v * d->m, 1, d->batch, &wsd)) != MPCX_OK) return rc;
+    if ((rc = ensure_lu_work(ctx, d->v * d->m, d->f * d->r, d->batch, &wsd)) != MPCX_OK) return rc;
+    if ((rc = ensure_lu_work(ctx, d->n, d->n, d->batch, &wsd)) != MPCX_OK) return rc;
+    QpArgs a{};
+    a.n = d->n; a.m = d->m; a.r = d->r; a.f = d->f; a.v = d->v; a.batch = d->batch; a.W = W; a.weights_mode = d->weights_mode;
+    if (!c2d_lane_supports(d->n, d->m)) {  // I - Ac dt of the general discretisation
+        const size_t need = (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n) * sizeof(double);
+        if (need > ctx->aux_bytes) {
+            if (ctx->aux) { HIP_TRY(ctx, hipFree(ctx->aux)); ctx->aux = nullptr; ctx->aux_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(&ctx->aux, need));
+            ctx->aux_bytes = need;
+        }
+    }
+    if (W != 1 && (!qp_lane_takes(a) || d->hessian_algo == MPCX_HESSIAN_CONTRACT)) {  // instance-major copy of a build
+        const long long n = d->n, m = d->m, r = d->r, FR = (long long)d->f * r, VM = (long long)d->v * m;
+        const long long per = n * n + n * m + r * n + n + FR + FR * n + FR * VM + VM * VM + VM;
+        if ((rc = ensure_relay(ctx, (size_t)relay_chunk(ctx, per, d->batch) * (size_t)per * sizeof(double))) != MPCX_OK) return rc;
     }
     return MPCX_OK;
 }

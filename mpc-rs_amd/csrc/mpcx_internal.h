@@ -54,6 +54,7 @@ int launch_solve_inplace(const double *H, double *X, int *info, long long batch,
                          size_t ws_doubles, hipStream_t s);
 int launch_c2d_lane(const double *Ac, const double *Bc, double dt, double *A, double *B, int *info, long long batch, long long W,
                     int n, int m, hipStream_t s);
+bool c2d_lane_supports(int n, int m);  // launch_c2d_lane takes the shape (no scratch needed)
 int launch_c2d_general(const double *Ac, const double *Bc, double dt, double *A, double *B, int *info, long long batch,
                        long long W, int n, int m, double *tmp, double *ws, size_t ws_doubles, hipStream_t s);
 // Static device scratch of the allocation-free discretisation: capacity in doubles, and its address on the current

@@ -11,6 +11,7 @@
 //   general n             M = I - Ac dt is formed elementwise, inverted by the batched solver (right-hand side I, in
 //                         place in the output A) and B = A (Bc dt) follows elementwise
 #include "mpcx_internal.h"
+#include "small_inverse.h"
 
 #include <mutex>
 
@@ -28,16 +29,45 @@ namespace {
 constexpr int kBlock = 64;
 constexpr double kNaN = __builtin_nan("");
 
-// A = (I - Ac dt)^-1 by Gauss-Jordan with partial pivoting, all in registers; B = A (Bc dt).
+// I - Ac dt with the product rounded before the subtraction, as `identity - mat_ac.scale(dt)` (model.rs:56, :139).
+__device__ __forceinline__ double one_minus_scaled(double id, double ac, double dt) {
+#pragma clang fp contract(off)
+    const double scaled = ac * dt;
+    return id - scaled;
+}
+
+// A = (I - Ac dt)^-1, all in registers; B = A (Bc dt).  Up to 4 states: the closed-form inverse nalgebra's try_inverse
+// takes for these sizes (singular when the determinant is exactly zero); above: Gauss-Jordan with partial pivoting.
 template <int N, int M>
 __device__ __forceinline__ bool c2d_regs(const double (&Ac)[N][N], const double (&Bc)[N][M], double dt, double (&A)[N][N],
                                          double (&B)[N][M]) {
     double a[N][N], inv[N][N];
+    if constexpr (N <= 4) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) a[i][j] = one_minus_scaled(i == j ? 1.0 : 0.0, Ac[i][j], dt);
+        const bool ok = inverse_closed_form<N>(a, inv);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) A[i][j] = ok ? inv[i][j] : kNaN;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) s += A[i][j] * (Bc[j][k] * dt);  // model.rs:57 / :140
+                B[i][k] = s;
+            }
+        return ok;
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            a[i][j] = (i == j ? 1.0 : 0.0) - Ac[i][j] * dt;  // model.rs:56 / :139
+            a[i][j] = one_minus_scaled(i == j ? 1.0 : 0.0, Ac[i][j], dt);
             inv[i][j] = (i == j ? 1.0 : 0.0);
         }
     bool ok = true;
@@ -206,12 +236,14 @@ int launch_c2d_one(const double *Ac, const double *Bc, double dt, double *A, dou
 
 }  // namespace
 
+bool c2d_lane_supports(int n, int m) { return (m == 1 && n >= 1 && n <= 6) || (m == 2 && (n == 2 || n == 3 || n == 4 || n == 6)); }
+
 int launch_c2d_lane(const double *Ac, const double *Bc, double dt, double *A, double *B, int *info, long long batch, long long W,
                     int n, int m, hipStream_t s) {
 #define CASE(N_, M_) \
     if (n == N_ && m == M_) return launch_c2d_one<N_, M_>(Ac, Bc, dt, A, B, info, batch, W, s);
     CASE(1, 1) CASE(2, 1) CASE(3, 1) CASE(4, 1) CASE(5, 1) CASE(6, 1)
-    CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(6, 2)
+    CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(6, 2)  // keep c2d_lane_supports in step with this list
 #undef CASE
     return MPCX_ERR_UNSUPPORTED;
 }

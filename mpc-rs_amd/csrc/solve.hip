@@ -2,15 +2,17 @@
 // augmented matrix [H | R] held in LDS, one wavefront per instance.
 //
 // Reference: src/control/controller.rs:93-96 (`(tmp1 + W3).try_inverse()` then `tmp2 * M^T * W4`: the gain matrix) and
-// :130-132 (u_seq = gain * s, first move applied).  nalgebra's try_inverse is an LU with partial pivoting that fails on
-// an exactly zero pivot; the same test (plus non-finite pivots) sets the per-instance `info` flag here, which is how
-// the batched call reports the reference's Err("Matrix inversion failed") without aborting the batch.
+// :130-132 (u_seq = gain * s, first move applied).  Above 4 unknowns nalgebra's try_inverse is an LU with partial
+// pivoting that fails on an exactly zero pivot; the same test (plus non-finite pivots) sets the per-instance `info` flag
+// here, which is how the batched call reports the reference's Err("Matrix inversion failed") without aborting the
+// batch.  Up to 4 unknowns try_inverse evaluates closed forms and fails on a zero determinant: solve_tiny_kernel.
 //   solve:  R = fvec (one column),        X = -H^-1 fvec = the optimal input sequence
 //   gain:   R = Gamma^T blockdiag(Q),     X = H^-1 Gamma^T W4 = the reference's gain_matrix
 #include <type_traits>
 #include <utility>
 
 #include "mpcx_internal.h"
+#include "small_inverse.h"
 
 namespace mpcx {
 namespace {
@@ -29,6 +31,54 @@ struct SolveArgs {
     const double *Q;
     int r;
 };
+
+// Systems of 1..4 unknowns: one lane per instance, the inverse in closed form (what nalgebra's try_inverse does for
+// these sizes: singular exactly when the determinant is zero), then X = +-H^-1 R column by column.
+template <int K>
+__global__ __launch_bounds__(kWave) void solve_tiny_kernel(SolveArgs p) {
+    const long long b = (long long)blockIdx.x * kWave + threadIdx.x;
+    if (b >= p.batch) return;
+    double a[K][K], inv[K][K];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int i = 0; i < K; ++i) a[i][j] = p.H[elem_index(b, j * K + i, K * K, p.W)];
+    const bool ok = inverse_closed_form<K>(a, inv);
+    const double sign = p.negate ? -1.0 : 1.0, nan = __longlong_as_double(0x7ff8000000000000LL);
+    const long long ER = (long long)K * p.nrhs;
+    for (int c = 0; c < p.nrhs; ++c) {
+        double rr[K];
+        if (p.Q) {  // column c = (block i, output a2) of Gamma^T blockdiag(Q)
+            const int i = c / p.r, a2 = c - i * p.r;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                double sum = 0.0;
+                for (int q = 0; q < p.r; ++q)
+                    sum += p.R[elem_index(b, (long long)k * p.nrhs + i * p.r + q, ER, p.W)] * p.Q[a2 * p.r + q];
+                rr[k] = sum;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) rr[k] = p.R[elem_index(b, (long long)c * K + k, ER, p.W)];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double x = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) x += inv[k][j] * rr[j];
+            p.X[elem_index(b, (long long)c * K + k, ER, p.W)] = ok ? sign * x : nan;
+        }
+    }
+    if (p.info) p.info[b] = ok ? 0 : 1;
+}
+
+template <int K>
+int launch_tiny(const SolveArgs &a, hipStream_t s) {
+    const long long blocks = (a.batch + kWave - 1) / kWave;
+    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(solve_tiny_kernel<K>, dim3((unsigned)blocks), dim3(kWave), 0, s, a);
+    return (int)hipGetLastError();
+}
 
 __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs p) {
     extern __shared__ double aug[];  // column-major [col][row], leading dimension ld (odd)
@@ -462,6 +512,10 @@ int launch_small(const SolveArgs &a, hipStream_t s) {
 }
 
 int launch_solve(const SolveArgs &a, hipStream_t s) {
+    if (a.nrow == 1) return launch_tiny<1>(a, s);
+    if (a.nrow == 2) return launch_tiny<2>(a, s);
+    if (a.nrow == 3) return launch_tiny<3>(a, s);
+    if (a.nrow == 4) return launch_tiny<4>(a, s);
     // the reference's horizon with rows in registers: gain of a single-output plant, and the solve
     if (a.nrow == 20 && a.nrhs == 20 && a.Q && a.r == 1 && a.R != a.X) return launch_rows<20, 20, 1>(a, s);
     if (a.nrow == 20 && a.nrhs == 1 && !a.Q && a.R != a.X) return launch_rows<20, 1, 0>(a, s);

@@ -22,10 +22,11 @@ ERR_NULL, ERR_DIMS, ERR_LAYOUT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_SINGULAR = -
 WEIGHTS_BLOCK, WEIGHTS_DENSE = 0, 1
 HESSIAN_AUTO, HESSIAN_CONTRACT, HESSIAN_STRUCTURED = 0, 1, 2
 PLANT_DC_MOTOR, PLANT_TWO_MASS = 0, 1
+OPT_RELAY_CAP_BYTES = 1
 
 # every symbol include/mpcx.h declares
 EXPORTS = (
-    "mpcx_version", "mpcx_array_elems", "mpcx_create", "mpcx_destroy", "mpcx_last_error",
+    "mpcx_version", "mpcx_array_elems", "mpcx_create", "mpcx_destroy", "mpcx_last_error", "mpcx_reserve", "mpcx_set_option",
     "mpcx_qp_build_f64", "mpcx_qp_build_f64_dev", "mpcx_rollout_f64", "mpcx_rollout_f64_dev",
     "mpcx_qp_solve_f64", "mpcx_qp_solve_f64_dev", "mpcx_qp_gain_f64", "mpcx_qp_gain_f64_dev",
     "mpcx_closed_loop_f64", "mpcx_closed_loop_f64_dev",
@@ -82,6 +83,10 @@ def lib() -> C.CDLL:
     lb.mpcx_destroy.restype = None
     lb.mpcx_last_error.argtypes = [vp]
     lb.mpcx_last_error.restype = C.c_char_p
+    lb.mpcx_reserve.argtypes = [vp, C.POINTER(Dims)]
+    lb.mpcx_reserve.restype = C.c_int
+    lb.mpcx_set_option.argtypes = [vp, C.c_int, i64]
+    lb.mpcx_set_option.restype = C.c_int
     lb.mpcx_qp_build_f64.argtypes = [vp, C.POINTER(Dims)] + [dp] * 11
     lb.mpcx_qp_build_f64.restype = C.c_int
     lb.mpcx_qp_build_f64_dev.argtypes = [vp, C.POINTER(Dims)] + [dp] * 11 + [vp]
@@ -168,6 +173,13 @@ class Context:
     def _check(self, rc: int):
         if rc != OK:
             raise MpcxError(rc, self._lib.mpcx_last_error(self._h).decode())
+
+    def reserve(self, dims: Dims):
+        """Grow every scratch buffer the `_dev` calls of `dims` need, so that they do not allocate afterwards."""
+        self._check(self._lib.mpcx_reserve(self._h, C.byref(dims)))
+
+    def set_option(self, option: int, value: int):
+        self._check(self._lib.mpcx_set_option(self._h, option, value))
 
     # ---- raw calls: pointers are ints / c_void_p (device) or numpy arrays (host) ----
     def qp_build_dev(self, dims: Dims, A, B, Cm, W3, W4, x0, ref, Phi, Gamma, H, fvec, stream=0):

@@ -23,6 +23,8 @@ def lib(variant: str = "") -> C.CDLL:
         return _LIBS[variant]
     name = "libmpc_oracle%s.so" % ("_" + variant if variant else "")
     path = os.path.join(_HERE, "_build", name)
+    if not variant and os.environ.get("MPC_ORACLE_LIB"):  # e.g. the sanitizer build of `make -C oracle asan`
+        path = os.environ["MPC_ORACLE_LIB"]
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
     L = C.CDLL(path)

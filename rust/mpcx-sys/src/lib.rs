@@ -22,6 +22,7 @@ pub const MPCX_HESSIAN_CONTRACT: i32 = 1;
 pub const MPCX_HESSIAN_STRUCTURED: i32 = 2;
 pub const MPCX_PLANT_DC_MOTOR: c_int = 0;
 pub const MPCX_PLANT_TWO_MASS: c_int = 1;
+pub const MPCX_OPT_RELAY_CAP_BYTES: c_int = 1;
 
 #[repr(C)]
 pub struct mpcx_ctx {
@@ -61,6 +62,8 @@ extern "C" {
     pub fn mpcx_create(out: *mut *mut mpcx_ctx, device_id: c_int) -> c_int;
     pub fn mpcx_destroy(ctx: *mut mpcx_ctx);
     pub fn mpcx_last_error(ctx: *const mpcx_ctx) -> *const c_char;
+    pub fn mpcx_reserve(ctx: *mut mpcx_ctx, dims: *const mpcx_dims) -> c_int;
+    pub fn mpcx_set_option(ctx: *mut mpcx_ctx, option: c_int, value: i64) -> c_int;
 
     pub fn mpcx_qp_build_f64(ctx: *mut mpcx_ctx, dims: *const mpcx_dims, a: *const f64, b: *const f64, c: *const f64,
         w3: *const f64, w4: *const f64, x0: *const f64, reference: *const f64, phi: *mut f64, gamma: *mut f64,

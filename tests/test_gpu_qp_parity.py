@@ -220,11 +220,11 @@ def test_interleaved_batches_on_the_instance_major_kernels(ctx, interleave, batc
         assert np.array_equal(part["Gamma"], base["Gamma"]) and np.array_equal(part["fvec"], base["fvec"])
         if batch == 200:  # a scratch cap of 3.5 instances' worth (test knob): the batch goes through in many chunks
             per = 8 * (n * n + n * m + r * n + n + f * r + f * r * n + f * r * v * m + (v * m) ** 2 + v * m)
-            os.environ["MPCX_RELAY_CAP_BYTES"] = str(int(3.5 * per))
+            ctx.set_option(ffi.OPT_RELAY_CAP_BYTES, int(3.5 * per))
             try:
                 chunked = _run(ctx, data, interleave)
             finally:
-                del os.environ["MPCX_RELAY_CAP_BYTES"]
+                ctx.set_option(ffi.OPT_RELAY_CAP_BYTES, 2 << 30)
             for k in ("Phi", "Gamma", "H", "fvec"):
                 assert np.array_equal(chunked[k], base[k]), f"chunked relay: {k} differs"
         if n == 8:
