@@ -81,6 +81,9 @@ def main():
                     help="N > 1: result array gathered to rank 0 over RCCL after the timed region (reported apart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances timed on the CPU (default: ~15 s worth)")
+    ap.add_argument("--lib-gather", action="store_true",
+                    help="N > 1: also exchange the records and gather fvec through the library's own RCCL communicator "
+                         "(mpcx_comm_*; always done at N = 1, where it is a one-rank communicator)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under \"also\"")
     ap.add_argument("--also-steps", type=int, default=5)
     args = ap.parse_args()
@@ -322,6 +325,38 @@ def main():
         except Exception as exc:  # the gather is a report, not the benchmark: never lose the line over it
             gathered = {"array": args.gather, "error": str(exc)[:200]}
 
+    # ---- the same exchange through the library's communicator (what a host without torch.distributed calls) ----
+    lib_gather = None
+    if world == 1 or args.lib_gather:
+        try:
+            cid = [ffi.comm_get_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(cid, src=0)
+            comm = ffi.Comm(ctx, cid[0], world, rank)
+            comm.gather_stats(check_buf.data_ptr(), check_buf.numel(), sp)  # first call: connection set-up
+            g0 = time.perf_counter()
+            recs2 = comm.gather_stats(check_buf.data_ptr(), check_buf.numel(), sp)
+            stats_ms = (time.perf_counter() - g0) * 1e3
+            src = outs.get("fvec", check_buf)
+            dst = torch.empty(src.numel() * world, dtype=torch.float64, device=dev) if rank == 0 else None
+            comm.gather_dev(src.data_ptr(), src.numel(), dst.data_ptr() if rank == 0 else None, 0, sp)
+            comm.synchronize()
+            g0 = time.perf_counter()
+            comm.gather_dev(src.data_ptr(), src.numel(), dst.data_ptr() if rank == 0 else None, 0, sp)
+            comm.synchronize()
+            arr_ms = (time.perf_counter() - g0) * 1e3
+            nbytes = src.numel() * 8
+            lib_gather = {"communicator": "mpcx_comm (RCCL, owned by libmpcx.so)", "world": world,
+                          "records_equal_torch_exchange": shard.merge_stats(recs2) == merged, "stats_ms": stats_ms,
+                          "array_bytes_per_rank": nbytes, "array_ms": arr_ms,
+                          "array_GB_per_s_into_rank0": nbytes * max(world - 1, 1) / arr_ms / 1e6}
+            if rank == 0:
+                lib_gather["self_check"] = bool(torch.equal(dst[rank * src.numel():(rank + 1) * src.numel()], src))
+            del dst
+            comm.close()
+        except Exception as exc:  # a report beside the benchmark: never lose the line over it
+            lib_gather = {"error": str(exc)[:200]}
+
     if rank == 0:
         total = per_gpu * world
         value = total * args.steps / elapsed
@@ -343,6 +378,8 @@ def main():
         }
         if gathered is not None:
             res["gather"] = gathered
+        if lib_gather is not None:
+            res["lib_gather"] = lib_gather
         if mfma_ms is not None:
             # The contraction kernel against the FP64 matrix-core peak.  `frac` counts the flops the kernel EXECUTES:
             # one v_mfma_f64_16x16x4_f64 is 2048 flops and the kernel issues a fixed number of them per instance

@@ -47,6 +47,7 @@ extern "C" {
 #define MPCX_ERR_UNSUPPORTED (-4) /* combination of dimensions / modes exceeds what the kernels hold on chip */
 #define MPCX_ERR_NO_DEVICE (-5)   /* no usable HIP device */
 #define MPCX_ERR_SINGULAR (-6)    /* reported per instance through `info`, see mpcx_qp_gain_* */
+#define MPCX_ERR_COMM (-7)        /* RCCL is missing or a communicator call failed, see mpcx_comm_last_error */
 
 #define MPCX_INTERLEAVE_FULL 0 /* W = batch */
 #define MPCX_INTERLEAVE_AOS 1  /* W = 1, instance-major */
@@ -242,6 +243,39 @@ int mpcx_closed_loop_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double 
 int mpcx_stats_f64_dev(mpcx_ctx *ctx, const double *buf, int64_t count, mpcx_stats *out_dev, void *stream);
 /* Same for a host-visible result: the record is copied to `out_host` and the call synchronises. */
 int mpcx_stats_f64(mpcx_ctx *ctx, const double *buf_dev, int64_t count, mpcx_stats *out_host);
+
+/*
+ * Multi-GPU exchange (no counterpart in the reference, which is single-threaded and device-less).  A batch is sharded
+ * by instance index, one rank per GPU -- a process per GPU, or a host thread per GPU with its own context -- and
+ * nothing is exchanged while the shards compute.  Afterwards the ranks exchange one mpcx_stats record each and, on
+ * request, gather a result array to one rank.  Both run over RCCL (xGMI inside a node) on a communicator that the
+ * library owns; RCCL (librccl.so.1) is loaded when the first of these functions is called, never before.
+ *
+ *   mpcx_comm_get_id    one rank (any) obtains MPCX_COMM_ID_BYTES opaque bytes and hands them to all other ranks
+ *                       through whatever channel the host has (a file, a socket, MPI, a parent process).
+ *   mpcx_comm_create    every rank, with its own context (the communicator uses that context's device), the same id,
+ *                       the number of ranks and its rank.  Collective: returns when all `world` ranks have called it.
+ *   mpcx_gather_stats   reduces `count` doubles at `buf_dev` (ordered after the work already queued on `stream`) to this
+ *                       rank's record and all-gathers the records: out_host receives `world` records in rank order, on
+ *                       every rank.  Collective; returns when the records are in out_host.
+ *   mpcx_gather_f64_dev gathers `count` doubles from every rank to dst_dev on `root` (world * count doubles, rank
+ *                       order; ignored on the other ranks).  Each rank sends straight to the root (point-to-point, one
+ *                       xGMI link per source), ordered after the work queued on `stream`; work queued on `stream`
+ *                       afterwards waits for the transfer.  Collective, asynchronous: mpcx_comm_synchronize waits.
+ * Errors: MPCX_ERR_COMM (text in mpcx_comm_last_error; with a NULL communicator it reports why RCCL could not be loaded).
+ * A communicator is used by one host thread at a time, like a context.
+ */
+#define MPCX_COMM_ID_BYTES 128
+typedef struct mpcx_comm mpcx_comm;
+int mpcx_comm_get_id(void *id_out);
+int mpcx_comm_create(mpcx_comm **out, mpcx_ctx *ctx, const void *id, int world, int rank);
+void mpcx_comm_destroy(mpcx_comm *comm);
+const char *mpcx_comm_last_error(const mpcx_comm *comm);
+int mpcx_comm_rank(const mpcx_comm *comm);
+int mpcx_comm_world(const mpcx_comm *comm);
+int mpcx_gather_stats(mpcx_comm *comm, const double *buf_dev, int64_t count, void *stream, mpcx_stats *out_host);
+int mpcx_gather_f64_dev(mpcx_comm *comm, const double *src_dev, int64_t count, double *dst_dev, int root, void *stream);
+int mpcx_comm_synchronize(mpcx_comm *comm);
 
 /*
  * Re-arranges a batched array between two interleave widths on the device (src and dst must not overlap).

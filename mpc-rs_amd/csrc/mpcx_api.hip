@@ -124,6 +124,10 @@ QpSizes qp_sizes(const mpcx_dims *d) {
 
 }  // namespace
 
+namespace mpcx {
+int ctx_device(const mpcx_ctx *ctx) { return ctx->device; }
+}  // namespace mpcx
+
 extern "C" {
 
 int mpcx_version(void) { return MPCX_VERSION; }

@@ -8,6 +8,9 @@
 
 namespace mpcx {
 
+// HIP device index a context is bound to.
+int ctx_device(const mpcx_ctx *ctx);
+
 // Arguments of one batched QP build; every pointer is a device pointer, W is the resolved interleave width
 // (1 <= W <= batch).
 struct QpArgs {

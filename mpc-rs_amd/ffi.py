@@ -33,7 +33,11 @@ EXPORTS = (
     "mpcx_c2d_backward_euler_f64", "mpcx_c2d_backward_euler_f64_dev", "mpcx_c2d_backward_euler_f64_noalloc_dev",
     "mpcx_plants_f64", "mpcx_plants_f64_dev",
     "mpcx_stats_f64_dev", "mpcx_stats_f64", "mpcx_relayout_f64_dev",
+    "mpcx_comm_get_id", "mpcx_comm_create", "mpcx_comm_destroy", "mpcx_comm_last_error", "mpcx_comm_rank", "mpcx_comm_world",
+    "mpcx_gather_stats", "mpcx_gather_f64_dev", "mpcx_comm_synchronize",
 )
+COMM_ID_BYTES = 128
+ERR_COMM = -7
 
 
 class MpcxError(RuntimeError):
@@ -123,8 +127,68 @@ def lib() -> C.CDLL:
     lb.mpcx_stats_f64.restype = C.c_int
     lb.mpcx_relayout_f64_dev.argtypes = [vp, i64, i64, i64, dp, i64, dp, vp]
     lb.mpcx_relayout_f64_dev.restype = C.c_int
+    lb.mpcx_comm_get_id.argtypes = [vp]
+    lb.mpcx_comm_get_id.restype = C.c_int
+    lb.mpcx_comm_create.argtypes = [C.POINTER(vp), vp, vp, C.c_int, C.c_int]
+    lb.mpcx_comm_create.restype = C.c_int
+    lb.mpcx_comm_destroy.argtypes = [vp]
+    lb.mpcx_comm_destroy.restype = None
+    lb.mpcx_comm_last_error.argtypes = [vp]
+    lb.mpcx_comm_last_error.restype = C.c_char_p
+    lb.mpcx_comm_rank.argtypes = [vp]
+    lb.mpcx_comm_rank.restype = C.c_int
+    lb.mpcx_comm_world.argtypes = [vp]
+    lb.mpcx_comm_world.restype = C.c_int
+    lb.mpcx_gather_stats.argtypes = [vp, dp, i64, vp, C.POINTER(Stats)]
+    lb.mpcx_gather_stats.restype = C.c_int
+    lb.mpcx_gather_f64_dev.argtypes = [vp, dp, i64, dp, C.c_int, vp]
+    lb.mpcx_gather_f64_dev.restype = C.c_int
+    lb.mpcx_comm_synchronize.argtypes = [vp]
+    lb.mpcx_comm_synchronize.restype = C.c_int
     _lib = lb
     return lb
+
+
+def comm_get_id() -> bytes:
+    """MPCX_COMM_ID_BYTES opaque bytes that one rank creates and every rank passes to Comm()."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().mpcx_comm_get_id(buf)
+    if rc != OK:
+        raise MpcxError(rc, lib().mpcx_comm_last_error(None).decode())
+    return buf.raw
+
+
+class Comm:
+    """One rank of the library's RCCL communicator, bound to a Context (its device)."""
+
+    def __init__(self, ctx: "Context", comm_id: bytes, world: int, rank: int):
+        assert len(comm_id) == COMM_ID_BYTES
+        self._lib = lib()
+        h = C.c_void_p()
+        rc = self._lib.mpcx_comm_create(C.byref(h), ctx._h, comm_id, world, rank)
+        if rc != OK:
+            raise MpcxError(rc, self._lib.mpcx_comm_last_error(None).decode() or "mpcx_comm_create failed")
+        self._h, self.world, self.rank = h, world, rank
+
+    def _check(self, rc: int):
+        if rc != OK:
+            raise MpcxError(rc, self._lib.mpcx_comm_last_error(self._h).decode())
+
+    def gather_stats(self, buf_dev, count: int, stream=0) -> list:
+        recs = (Stats * self.world)()
+        self._check(self._lib.mpcx_gather_stats(self._h, buf_dev, count, stream, recs))
+        return [r.as_dict() for r in recs]
+
+    def gather_dev(self, src_dev, count: int, dst_dev, root=0, stream=0):
+        self._check(self._lib.mpcx_gather_f64_dev(self._h, src_dev, count, dst_dev, root, stream))
+
+    def synchronize(self):
+        self._check(self._lib.mpcx_comm_synchronize(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mpcx_comm_destroy(self._h)
+            self._h = None
 
 
 def _hp(a):

@@ -12,6 +12,8 @@ pub const MPCX_ERR_LAYOUT: c_int = -3;
 pub const MPCX_ERR_UNSUPPORTED: c_int = -4;
 pub const MPCX_ERR_NO_DEVICE: c_int = -5;
 pub const MPCX_ERR_SINGULAR: c_int = -6;
+pub const MPCX_ERR_COMM: c_int = -7;
+pub const MPCX_COMM_ID_BYTES: usize = 128;
 
 pub const MPCX_INTERLEAVE_FULL: i64 = 0;
 pub const MPCX_INTERLEAVE_AOS: i64 = 1;
@@ -26,6 +28,11 @@ pub const MPCX_OPT_RELAY_CAP_BYTES: c_int = 1;
 
 #[repr(C)]
 pub struct mpcx_ctx {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct mpcx_comm {
     _private: [u8; 0],
 }
 
@@ -108,6 +115,17 @@ extern "C" {
     pub fn mpcx_stats_f64_dev(ctx: *mut mpcx_ctx, buf: *const f64, count: i64, out_dev: *mut mpcx_stats,
         stream: *mut c_void) -> c_int;
     pub fn mpcx_stats_f64(ctx: *mut mpcx_ctx, buf_dev: *const f64, count: i64, out_host: *mut mpcx_stats) -> c_int;
+    pub fn mpcx_comm_get_id(id_out: *mut c_void) -> c_int;
+    pub fn mpcx_comm_create(out: *mut *mut mpcx_comm, ctx: *mut mpcx_ctx, id: *const c_void, world: c_int, rank: c_int) -> c_int;
+    pub fn mpcx_comm_destroy(comm: *mut mpcx_comm);
+    pub fn mpcx_comm_last_error(comm: *const mpcx_comm) -> *const c_char;
+    pub fn mpcx_comm_rank(comm: *const mpcx_comm) -> c_int;
+    pub fn mpcx_comm_world(comm: *const mpcx_comm) -> c_int;
+    pub fn mpcx_gather_stats(comm: *mut mpcx_comm, buf_dev: *const f64, count: i64, stream: *mut c_void,
+        out_host: *mut mpcx_stats) -> c_int;
+    pub fn mpcx_gather_f64_dev(comm: *mut mpcx_comm, src_dev: *const f64, count: i64, dst_dev: *mut f64, root: c_int,
+        stream: *mut c_void) -> c_int;
+    pub fn mpcx_comm_synchronize(comm: *mut mpcx_comm) -> c_int;
     pub fn mpcx_relayout_f64_dev(ctx: *mut mpcx_ctx, batch: i64, elems_per_instance: i64, src_interleave: i64,
         src: *const f64, dst_interleave: i64, dst: *mut f64, stream: *mut c_void) -> c_int;
 }
