@@ -16,10 +16,10 @@
 // Loads and stores of one wave retire through a single in-order counter, so a wave that has stores in flight
 // waits for all of them before a later load returns.  The four compute waves therefore never load from global
 // memory once their first store is out: everything they need is in LDS, and the shared weight W3 (dense,
-// (v m)^2, far larger than LDS) is streamed column block by column block into an LDS ring by three more waves
+// (v m)^2, far larger than LDS) is streamed column block by column block into an LDS ring by four more waves
 // that never store to it: each holds its share of up to eight blocks in flight in registers, so that a fetch has
 // several sweep steps to arrive (a CU's vector-memory pipeline is in order: loads queue behind the store stream).
-// The same three waves form fvec while the compute waves write Gamma.
+// The same four waves form fvec while the compute waves write Gamma.
 //
 // Reference math: src/control/controller.rs:32-44 (Phi), :46-90 (Gamma), :92-93 (H), :96 and :125-127 (fvec).
 #include <limits.h>
@@ -33,8 +33,15 @@ namespace mpcx {
 namespace {
 
 constexpr int kCompute = 256;            // threads that compute and store
-constexpr int kLoaders = 3;               // loader waves: each fetches every kLoaders-th column block of W3
+#ifndef MPCX_WG_LOADERS
+#define MPCX_WG_LOADERS 4
+#endif
+#ifndef MPCX_WG_RECUR_ALL
+#define MPCX_WG_RECUR_ALL 1
+#endif
+constexpr int kLoaders = MPCX_WG_LOADERS; // loader waves: each fetches every kLoaders-th column block of W3
 constexpr int kWgBlock = kCompute + 64 * kLoaders;
+constexpr int kRecur = MPCX_WG_RECUR_ALL ? kWgBlock : kCompute;  // threads that take a task of the recurrences
 constexpr int kCoef = 16;                // recurrence coefficients a thread keeps in registers (n <= kCoef)
 
 struct WgLds {
@@ -48,8 +55,8 @@ struct WgLds {
 // thread and divide f.  with_s: the s = Phi x0 - ref tasks ride along (fvec requested).
 __host__ __device__ inline int wg_stride(int n, int m, int r, int f, bool with_s) {
     const int per = r * m + r * n + (with_s ? r : 0), nW = n * m;
-    if (f % 4 == 0 && 4 * per + nW <= kCompute) return 4;
-    if (f % 2 == 0 && 2 * per + nW <= kCompute) return 2;
+    if (f % 4 == 0 && 4 * per + nW <= kRecur) return 4;
+    if (f % 2 == 0 && 2 * per + nW <= kRecur) return 2;
     return 1;
 }
 
@@ -71,13 +78,15 @@ __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v
     L.Pst = o; o += 2 * r * n;   // Phi state, ping-pong
     L.Sr = o; o += fr;           // ref, then Phi x0 - ref
     L.Z = o; o += fr;            // Q (Phi x0 - ref)
-    // strided recurrences only (the stride without the s tasks is the larger of the two): A^2..A^4, C A..C A^3, A x0..A^4 x0
-    L.Pow = o; o += wg_stride(n, m, r, f, false) > 1 ? 3 * n * n + 3 * r * n + 4 * n : 0;
+    // strided recurrences only (the stride without the s tasks is the larger of the two): A^2..A^4, C A..C A^3, A x0..A^4 x0.
+    // They are dead when the recurrences end, before Q G is formed: they borrow its space when it is large enough.
+    const int pow_sz = wg_stride(n, m, r, f, false) > 1 ? 3 * n * n + 3 * r * n + 4 * n : 0;
+    if (pow_sz <= m * fr) { L.Pow = L.QG; } else { L.Pow = o; o += pow_sz; }
     const int end1 = o;
     o = u;
-    L.Hp = o; o += 2 * v * m * m;   // column block of H (without W3), ping-pong: [slot][i*m + j][a]
-    L.W3r = o; o += 2 * v * m * m;  // ring of two column blocks of W3: [slot][j][row]
-    L.Tab = o; o += (f > v) ? 2 * v * m * m : 0;  // held-input case only: first swept column and Toeplitz seed row
+    L.Hp = o; o += 2 * (v + 1) * m * m;  // column block of the swept Gram matrix, ping-pong: [slot][i*m + j][a], a = 0..v
+    L.W3r = o; o += 2 * v * m * m;       // ring of two column blocks of W3: [slot][j][row]
+    L.Tab = o; o += (f > v) ? (v + 1) * m * m : 0;  // held-input case only: the virtual block row, [i*m + j][b']
     L.total = o > end1 ? o : end1;
     return L;
 }
@@ -106,45 +115,101 @@ __device__ inline double h_direct(const double *sG, const double *sS, const doub
     return (a[0] + a[1]) + (a[2] + a[3]);
 }
 
-// The whole M x M block (aa, bb) at once: out[i][j] as h_direct would give it (up to the order of the partial sums).
-// Every operand read serves M multiply-adds instead of one, which is what matters: the direct sums are bound by LDS
-// reads.  Two terms of the sum are in flight together.
-template <int M>
-__device__ __forceinline__ void h_direct_block(const double *sG, const double *sS, const double *sQG, const double *sQS, int aa,
-                                               int bb, int f, int v, int r, int FR, int nl, bool use_s, double (&out)[M][M]) {
-    const bool la = use_s && (aa == v - 1), lb = use_s && (bb == v - 1);
-    const int i0 = aa > bb ? aa : bb;
-    const double *ga = la ? (sS + (i0 - (v - 1)) * r) : (sG + (i0 - aa) * r);
-    const double *qb = lb ? (sQS + (i0 - (v - 1)) * r) : (sQG + (i0 - bb) * r);
-    const int sa = la ? nl * r : FR, sb = lb ? nl * r : FR;  // distance between the vectors of two columns
-    const int len = (f - i0) * r;
-    double acc0[M][M], acc1[M][M];
+// Held inputs (f > v): what the sweep's recurrence cannot produce are families of short sums over the block rows
+// i2 >= v-1 (L = f - v + 1 of them): the virtual block column and row that border the swept Gram matrix Ht,
+//     Ht[a'][v] = sum_(i2 >= v) G_(i2-a')^T Q G_(i2-v),     Ht[v][b'] = sum_(i2 >= v) G_(i2-v)^T Q G_(i2-b')      (L - 1 terms)
+// and the last block column and row of H itself, which involve the held-input column S (L terms).  With d = v - a'
+// (resp. v - b', v-1-a, v-1-b) all of them are two products with one shifted (Hankel) operand, contraction index
+// k = (jj, rho):
+//     Z1[(d,c)][j] = sum_k G_(jj+d)[rho][c]  . [Q G_jj | Q S_jj][rho][j]   -> Ht[a'][v] | H[a][v-1]   (row c, column j)
+//     Z2[(d,c)][i] = sum_k QG_(jj+d)[rho][c] . [G_jj   | S_jj  ][rho][i]   -> Ht[v][b'] | H[v-1][b]   (row i, column c)
+// (k < (L-1) r for the plain columns, k < K = L r for the cumulated ones), plus the corner H[v-1][v-1] = sum S^T Q S,
+// which is Z1 with operand rows S_jj.  Both operands of a row or column are contiguous in k in LDS (G, S, QG, QS are
+// stored one vector per input column), so every operand of v_mfma_f64_16x16x4_f64 is one LDS read.
+// The right operand has only 2 m columns.  A shift of d by one is a shift of k by r in the Hankel operand, so ND =
+// 16 / (2 m) consecutive values of d share one operand row: operand row (dq, c) is G[c][dq ND r + k'], k' < K + (ND-1) r,
+// and column (dd, j) of the right operand is column j delayed by dd r (zero outside its range); the product then holds
+// Z[(dq ND + dd, c)][j] in column (dd, j), and all 16 columns of the matrix core are used.  A wavefront takes 16 operand
+// rows at a time, all wavefronts of the workgroup take part.  Needs 2 m <= 16.
+// Results: the border goes to LDS (vcol: the column block the first sweep step reads as its predecessor; vrow: the
+// table the last block row reads; both [i*m + j][block index], v + 1 entries each); H's last block column and row go
+// straight to memory with their share of W3 (the sweep skips those positions).
+typedef double d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void held_sums_mfma(const double *sG, const double *sS, const double *sQG, const double *sQS,
+                                               double *vcol, double *vrow, double *gH, const double *gW3, int m, int r,
+                                               int f, int v, int tid) {
+    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, nwaves = kWgBlock >> 6;
+    const int FR = f * r, nl = f - v + 1, K = nl * r, VM = v * m, ldh = v + 1;
+    const int ND = 16 / (2 * m), NQ = (v + ND - 1) / ND;        // values of d per operand row, operand row groups
+    const int rows = (NQ + 1) * m, nt = (rows + 15) >> 4;       // the last m rows are the S rows of the corner
+    const int Kx = K + (ND - 1) * r;                            // contraction length with the delayed columns
+    // right-operand column of this lane: (dd, jt); jt < m pairs with the plain Markov vectors, else with the cumulated ones
+    const int dd = l15 / (2 * m), jt = l15 - dd * 2 * m;
+    const bool bok = dd < ND, bg = jt < m;
+    const int jb = bg ? jt : jt - m;
+    const int koff = dd * r, kend = koff + (bg ? K - r : K);    // this column is non-zero for koff <= k' < kend
+    const double *b1 = (bg ? sQG + jb * FR : sQS + jb * K) - koff;
+    const double *b2 = (bg ? sG + jb * FR : sS + jb * K) - koff;
+    for (int tile = wave; tile < nt; tile += nwaves) {
+        const int R = tile * 16 + l15;
+        const bool rowok = R < rows;
+        const int dq = rowok ? R / m : 0, c = rowok ? R - dq * m : 0;
+        const bool srow = (dq == NQ);
+        const double *a1 = srow ? sS + c * K : sG + c * FR + dq * ND * r;
+        const double *a2 = srow ? sQS + c * K : sQG + c * FR + dq * ND * r;
+        const int klim = srow ? K : Kx;  // (rows whose d runs past v-1 read on into the next vector: finite, discarded)
+        // where this lane's four results go: memory (with W3, read now and used after the contraction) or the border
+        double w3a[4], w3b[4];
+        long long ea[4], eb[4];
+        int ta[4];
 #pragma unroll
-    for (int i = 0; i < M; ++i)
+        for (int reg = 0; reg < 4; ++reg) {
+            const int Ri = tile * 16 + kq + 4 * reg;
+            const int dqi = Ri / m, ci = Ri - dqi * m, di = dqi * ND + dd;
+            ea[reg] = eb[reg] = -1;
+            ta[reg] = -1;
+            if (Ri < rows && bok) {
+                if (dqi == NQ) {
+                    if (dd == 0 && !bg) ea[reg] = (long long)((v - 1) * m + jb) * VM + (v - 1) * m + ci;  // corner
+                } else if (di < v) {
+                    if (bg) ta[reg] = v - di;  // a' resp. b'
+                    else if (di > 0) {
+                        ea[reg] = (long long)((v - 1) * m + jb) * VM + (v - 1 - di) * m + ci;  // H[a][v-1][ci][jb]
+                        eb[reg] = (long long)((v - 1 - di) * m + ci) * VM + (v - 1) * m + jb;  // H[v-1][b][jb][ci]
+                    }
+                }
+            }
+            w3a[reg] = ea[reg] >= 0 ? gW3[ea[reg]] : 0.0;
+            w3b[reg] = eb[reg] >= 0 ? gW3[eb[reg]] : 0.0;
+        }
+        d4 acc1 = (d4){0.0, 0.0, 0.0, 0.0}, acc2 = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < Kx; k0 += 8) {  // two steps of four per round: the eight LDS reads are in flight together
+            const int ka = k0 + kq, kb = k0 + 4 + kq;
+            const bool ra = rowok && ka < klim, rb = rowok && kb < klim;
+            const bool ca = bok && ka >= koff && ka < kend, cb = bok && kb >= koff && kb < kend;
+            const int ia = ra ? ka : 0, ib = rb ? kb : 0, ja = ca ? ka : koff, jbk = cb ? kb : koff;
+            double x1a = a1[ia], y1a = b1[ja], x2a = a2[ia], y2a = b2[ja];
+            double x1b = a1[ib], y1b = b1[jbk], x2b = a2[ib], y2b = b2[jbk];
+            x1a = ra ? x1a : 0.0; x2a = ra ? x2a : 0.0; y1a = ca ? y1a : 0.0; y2a = ca ? y2a : 0.0;
+            x1b = rb ? x1b : 0.0; x2b = rb ? x2b : 0.0; y1b = cb ? y1b : 0.0; y2b = cb ? y2b : 0.0;
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1a, y1a, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2a, y2a, acc2, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1b, y1b, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2b, y2b, acc2, 0, 0, 0);
+        }
+        // D[i][j]: this lane holds column j = l15 and rows i = kq + 4 reg of the tile
 #pragma unroll
-        for (int j = 0; j < M; ++j) acc0[i][j] = acc1[i][j] = 0.0;
-    int t = 0;
-    for (; t + 1 < len; t += 2) {
-        double x0[M], x1[M], y0[M], y1[M];
-#pragma unroll
-        for (int i = 0; i < M; ++i) { x0[i] = ga[i * sa + t]; x1[i] = ga[i * sa + t + 1]; }
-#pragma unroll
-        for (int j = 0; j < M; ++j) { y0[j] = qb[j * sb + t]; y1[j] = qb[j * sb + t + 1]; }
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-            for (int j = 0; j < M; ++j) { acc0[i][j] += x0[i] * y0[j]; acc1[i][j] += x1[i] * y1[j]; }
+        for (int reg = 0; reg < 4; ++reg) {
+            const int Ri = tile * 16 + kq + 4 * reg;
+            const int ci = Ri % m;
+            if (ta[reg] >= 0) {
+                vcol[(ci * m + jb) * ldh + ta[reg]] = acc1[reg];  // Ht[a'][v][ci][jb]
+                vrow[(jb * m + ci) * ldh + ta[reg]] = acc2[reg];  // Ht[v][b'][jb][ci]
+            }
+            if (ea[reg] >= 0) gH[ea[reg]] = acc1[reg] + w3a[reg];
+            if (eb[reg] >= 0) gH[eb[reg]] = acc2[reg] + w3b[reg];
+        }
     }
-    if (t < len) {
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-            for (int j = 0; j < M; ++j) acc0[i][j] += ga[i * sa + t] * qb[j * sb + t];
-    }
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-        for (int j = 0; j < M; ++j) out[i][j] = acc0[i][j] + acc1[i][j];
 }
 
 // The loader waves' W3 pipeline.  Step s of the sweep (s = 0 .. v-1) uses column block v-1-s of W3 (wcnt doubles,
@@ -395,7 +460,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         }
         lds_barrier();
     }
-    const bool one_task = (nT <= kCompute) && (n <= kCoef);
+    const bool one_task = (nT <= kRecur) && (n <= kCoef);
     if (one_task) {
         // Stride: the recurrences are a serial chain of f steps, one LDS round trip and one barrier each.  Where the
         // threads allow it a step advances the states by A^st (st = 4 or 2) and produces the st Markov blocks, Phi
@@ -442,7 +507,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         double coef[kCoef];
 #pragma unroll
         for (int j = 0; j < kCoef; ++j) coef[j] = 0.0;
-        if (!loader && tid < nTs) {
+        if (tid < kRecur && tid < nTs) {
             if (tid < tG) {
                 const int jj = tid / nG, u = tid - jj * nG, a = u % r, c = u / r;
                 const double *X = CApow(jj);
@@ -642,34 +707,34 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             double *dst = sW3 + ((v - 1) & 1) * wcnt, *oth = sW3 + (v & 1) * wcnt;
             for (int e = tid - kCompute; e < wcnt; e += 64 * kLoaders) { dst[e] = src[e]; oth[e] = 0.0; }
         }
-        const int bsz = m * m, tsz = v * bsz;
+        // The sweep runs on the Gram matrix Ht of plain-shift columns, Ht[a][b] = Ht[a+1][b+1] + G_(f-1-a)^T Q G_(f-1-b),
+        // bordered by a virtual block row and column of index v: zero when f = v, and for f > v the short sums
+        //     Ht[a'][v] = sum_(i2 >= v) G_(i2-a')^T Q G_(i2-v),   Ht[v][b'] = sum_(i2 >= v) G_(i2-v)^T Q G_(i2-b')   (a', b' = 1..v)
+        // With the border in place every block of every step is the same recurrence: no first-column or last-row case.
+        // A column block of Ht is kept as [i*m + j][a], a = 0..v (ldh = v + 1 entries, the last one the virtual row).
+        // The virtual column is the "previous column" of the first step; the virtual row sits in a table of the same
+        // layout (sVrow, entry b' for column block b'), from which the last block row reads its predecessor.
+        // For f > v the last block row and column of H itself involve the held-input column and are not swept: they are
+        // summed (with the border, on the matrix cores where 2 m <= 16) and stored before or after the sweep.
+        const int bsz = m * m, ldh = v + 1, slot = bsz * ldh;
         const bool held = HM > 0 ? HELD : nl > 1;
-        // f > v: the sweep runs on the Gram matrix Ht of plain-shift columns.  Its column block v-1 (where the sweep
-        // starts) and its block row v-1 (the seed of every later column) are short direct sums (f - v + 1 terms), kept
-        // in two tables.  The last block row and column of H itself, which involve the held-input column, are not part
-        // of the sweep at all: they are summed and stored after it.
-        if constexpr (HM > 0) {
-            if (held) {  // one block per thread
-                for (int t = tid; t < 2 * v; t += kWgBlock) {
-                    const int which = t / v, blk = t - which * v;
-                    double blkv[HM][HM];
-                    h_direct_block<HM>(sG, sS, sQG, sQS, which == 0 ? blk : v - 1, which == 0 ? v - 1 : blk, f, v, r, FR, nl, false, blkv);
-#pragma unroll
-                    for (int i = 0; i < HM; ++i)
-#pragma unroll
-                        for (int j = 0; j < HM; ++j) sTab[which * tsz + (blk * HM + i) * HM + j] = blkv[i][j];
-                }
-            }
-        } else if (held) {
-            for (int t = tid; t < 2 * tsz; t += kWgBlock) {
-                const int which = t / tsz, rem = t - which * tsz, blk = rem / bsz, ij = rem - blk * bsz;
-                const int i = ij / m, j = ij - i * m;
-                sTab[t] = which == 0 ? h_direct(sG, sS, sQG, sQS, blk, v - 1, i, j, f, v, r, FR, nl, false)
-                                     : h_direct(sG, sS, sQG, sQS, v - 1, blk, i, j, f, v, r, FR, nl, false);
-            }
-        }
-        const double *tabFirst = sTab, *tabSeed = sTab + tsz;
+        const bool mfma_sums = held && 2 * m <= 16;
+        double *sVrow = sTab;
         double *gH = p.H + b * (long long)VM * VM;
+        double *first_prev = sHp + (v & 1) * slot;  // what step bb = v-1 reads as its previous column
+        if (mfma_sums) {
+            held_sums_mfma(sG, sS, sQG, sQS, first_prev, sVrow, gH, p.W3, m, r, f, v, tid);
+        } else if (held) {
+            for (int t = tid; t < 2 * v * bsz; t += kWgBlock) {
+                const int which = t / (v * bsz), rem = t - which * (v * bsz), blk = 1 + rem / bsz, ij = rem % bsz;
+                const int i = ij / m, j = ij - i * m;
+                if (which == 0) first_prev[ij * ldh + blk] = h_direct(sG, sS, sQG, sQS, blk, v, i, j, f, v, r, FR, nl, false);
+                else sVrow[ij * ldh + blk] = h_direct(sG, sS, sQG, sQS, v, blk, i, j, f, v, r, FR, nl, false);
+            }
+        } else {
+            for (int e = tid; e < slot; e += kWgBlock) first_prev[e] = 0.0;
+            for (int e = tid; e < bsz; e += kWgBlock) sHp[((v - 1) & 1) * slot + e * ldh + v] = 0.0;
+        }
 
         if constexpr (HM > 0) {
             // item it of this thread: column j of block row aa, t = tid + it * kCompute = j * v + aa
@@ -696,10 +761,9 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             } else {
                 STAMP(6);
                 for (int bb = v - 1; bb >= 0; --bb) {
-                    double *cur = sHp + (bb & 1) * VM * m;
-                    const double *prev = sHp + ((bb + 1) & 1) * VM * m;
+                    double *cur = sHp + (bb & 1) * slot;
+                    const double *prev = sHp + ((bb + 1) & 1) * slot;
                     const double *w3 = sW3 + (bb & 1) * VM * m;
-                    const bool first = (bb == v - 1);
                     if (bb == v / 2) STAMP(7);
                     // Three passes over the thread's items, two items at a time -- every LDS read, then the arithmetic,
                     // then the LDS writes and the stores -- so that the reads of a pair are in flight together (one LDS
@@ -712,14 +776,13 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                     for (int ic = 0; ic < CH; ++ic) {
                         const int it = c0 + ic;
                         const int j = item_j[it] < 0 ? 0 : item_j[it], aa = item_aa[it];
-                        const bool lastrow = (aa == v - 1);
-                        const int an = lastrow ? aa : aa + 1;
+                        // predecessor Ht[aa+1][bb+1]: the previous column, or for the last block row (f > v) the virtual row
+                        const double *src = (HELD && aa == v - 1) ? sVrow + j * ldh + bb + 1 : prev + j * ldh + aa + 1;
                         const double *qb = sQG + j * FR + (f - 1 - bb) * HR;
                         const double *wsrc = w3 + j * VM + aa * HM;
 #pragma unroll
                         for (int i = 0; i < HM; ++i) {
-                            const double pv = prev[(i * HM + j) * v + an];
-                            acc[ic][i] = (first || lastrow) ? 0.0 : pv;
+                            acc[ic][i] = src[i * HM * ldh];
                             w3v[ic][i] = wsrc[i];
                         }
 #pragma unroll
@@ -728,36 +791,24 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
 #pragma unroll
                     for (int ic = 0; ic < CH; ++ic) {
                         const int it = c0 + ic;
-                        const int j = item_j[it] < 0 ? 0 : item_j[it], aa = item_aa[it];
-                        const bool lastrow = (aa == v - 1);
-                        if (first && held) {
 #pragma unroll
-                            for (int i = 0; i < HM; ++i) acc[ic][i] = tabFirst[(aa * HM + i) * HM + j];
-                        } else {
+                        for (int q = 0; q < HR; ++q)
 #pragma unroll
-                            for (int q = 0; q < HR; ++q)
-#pragma unroll
-                                for (int i = 0; i < HM; ++i) acc[ic][i] += ga[it][q][i] * qv[ic][q];
-                            if (held && lastrow) {
-#pragma unroll
-                                for (int i = 0; i < HM; ++i) acc[ic][i] = tabSeed[(bb * HM + i) * HM + j];
-                            }
-                        }
+                            for (int i = 0; i < HM; ++i) acc[ic][i] += ga[it][q][i] * qv[ic][q];
                     }
 #pragma unroll
                     for (int ic = 0; ic < CH; ++ic) {
                         const int it = c0 + ic;
                         const int j = item_j[it], aa = item_aa[it];
                         if (j < 0) continue;
-                        const bool lastrow = (aa == v - 1);
                         double *dst = gH + (long long)(bb * HM + j) * VM + aa * HM;
                         double out[HM];
 #pragma unroll
                         for (int i = 0; i < HM; ++i) {
-                            cur[(i * HM + j) * v + aa] = acc[ic][i];
+                            cur[(i * HM + j) * ldh + aa] = acc[ic][i];
                             out[i] = acc[ic][i] + w3v[ic][i];
                         }
-                        if (held && (first || lastrow)) continue;  // H's last block row / column: after the sweep
+                        if (HELD && (bb == v - 1 || aa == v - 1)) continue;  // H's last block row / column: not swept
                         if constexpr (HM % 2 == 0) {
 #pragma unroll
                             for (int i = 0; i < HM; i += 2) *(double2 *)(dst + i) = make_double2(out[i], out[i + 1]);
@@ -772,34 +823,25 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             }
         } else {
             lds_barrier();
-            // Two loops with the same number of barriers: the loader wave's and the compute waves'.  Keeping them
-            // apart keeps the loader's fetch registers and the compute waves' G blocks out of each other's live ranges.
+            // Two loops with the same number of barriers: the loader wave's and the compute waves'.
             if (loader) {
                 w3_loader_run(p.W3, sW3, (const int *)p.w3win, v, m, lw, ltid, wide);
             } else {
                 for (int bb = v - 1; bb >= 0; --bb) {
-                    double *cur = sHp + (bb & 1) * VM * m;
-                    const double *prev = sHp + ((bb + 1) & 1) * VM * m;
+                    double *cur = sHp + (bb & 1) * slot;
+                    const double *prev = sHp + ((bb + 1) & 1) * slot;
                     const double *w3 = sW3 + (bb & 1) * VM * m;
-                    const bool first = (bb == v - 1);
                     for (int t = tid; t < VM; t += kCompute) {  // t = j * v + aa, as in the specialised sweep
                         const int j = t / v, aa = t - j * v;
                         const bool lastrow = (aa == v - 1);
-                        const int an = lastrow ? aa : aa + 1;
+                        const double *src = (held && lastrow) ? sVrow + j * ldh + bb + 1 : prev + j * ldh + aa + 1;
                         const double *qb = sQG + j * FR + (f - 1 - bb) * r;
                         for (int i = 0; i < m; ++i) {
-                            double acc;
-                            if (first && held) {
-                                acc = tabFirst[(aa * m + i) * m + j];
-                            } else {
-                                const double pv = prev[(i * m + j) * v + an];
-                                acc = (first || lastrow) ? 0.0 : pv;
-                                const double *ga = sG + i * FR + (f - 1 - aa) * r;
-                                for (int q = 0; q < r; ++q) acc += ga[q] * qb[q];
-                                if (held && lastrow) acc = tabSeed[(bb * m + i) * m + j];
-                            }
-                            cur[(i * m + j) * v + aa] = acc;
-                            if (held && (first || lastrow)) continue;  // H's last block row / column: after the sweep
+                            double acc = src[i * m * ldh];
+                            const double *ga = sG + i * FR + (f - 1 - aa) * r;
+                            for (int q = 0; q < r; ++q) acc += ga[q] * qb[q];
+                            cur[(i * m + j) * ldh + aa] = acc;
+                            if (held && (bb == v - 1 || lastrow)) continue;  // H's last block row / column: not swept
                             gH[(long long)(bb * m + j) * VM + aa * m + i] = acc + w3[j * VM + aa * m + i];
                         }
                     }
@@ -807,26 +849,11 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                 }
             }
         }
-        // f > v: last block column (which = 0) and last block row (which = 1) of H, with the held-input column S in
-        // place of a plain shift, summed directly (f - v + 1 terms each) and stored with their share of W3.  The two
-        // meet in the corner block with the same value.
-        if constexpr (HM > 0) {
-            if (held) {
-                for (int t = tid; t < 2 * v; t += kWgBlock) {
-                    const int which = t / v, blk = t - which * v;
-                    const int ba = which == 0 ? blk : v - 1, bbk = which == 0 ? v - 1 : blk;  // block row, block column
-                    double blkv[HM][HM];
-                    h_direct_block<HM>(sG, sS, sQG, sQS, ba, bbk, f, v, r, FR, nl, true, blkv);
-#pragma unroll
-                    for (int j = 0; j < HM; ++j)
-#pragma unroll
-                        for (int i = 0; i < HM; ++i) {
-                            const long long e = (long long)(bbk * HM + j) * VM + ba * HM + i;
-                            gH[e] = blkv[i][j] + p.W3[e];
-                        }
-                }
-            }
-        } else if (held) {
+        // f > v without the matrix-core path (m > 8): last block column (which = 0) and last block row (which = 1) of H,
+        // with the held-input column S in place of a plain shift, summed directly (f - v + 1 terms each) and stored with
+        // their share of W3.  The two meet in the corner block with the same value.
+        if (held && !mfma_sums) {
+            const int tsz = v * bsz;
             for (int t = tid; t < 2 * tsz; t += kWgBlock) {
                 const int which = t / tsz, rem = t - which * tsz, blk = rem / bsz, ij = rem - blk * bsz;
                 const int i = ij / m, j = ij - i * m;

@@ -10,7 +10,9 @@ dev = torch.device("cuda", 0)
 ctx = ffi.Context(0)
 wl = synth.WORKLOADS[name]
 n, m, r, f, v = wl["n"], wl["m"], wl["r"], wl["f"], wl["v"]
-d = synth.make_batch(name, count)
+if len(sys.argv) > 5:  # optional horizon override: f v
+    f, v = int(sys.argv[4]), int(sys.argv[5])
+d = synth.make_batch(name, count, f=f, v=v)
 sizes = {"Phi": f * r * n, "Gamma": f * r * v * m, "H": v * m * v * m, "fvec": v * m}
 for il in [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "4096"])]:
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -19,7 +21,7 @@ for il in [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0
     bufs["W3"] = to(L.colmajor(d["W3"])); bufs["Q"] = to(L.colmajor(d["Q"]))
     outs = {k: torch.empty(L.array_elems(count, il, e), dtype=torch.float64, device=dev) for k, e in sizes.items()}
     dims = ffi.make_dims(n, m, r, f, v, count, 0, il)
-    for subset in [("Phi",), ("Gamma",), ("H",), ("fvec",), ("Gamma", "H"), ("Phi", "Gamma", "H", "fvec")]:
+    for subset in [("Phi",), ("Gamma",), ("H",), ("fvec",), ("Gamma", "H"), ("Phi", "Gamma", "H"), ("Phi", "Gamma", "H", "fvec")]:
         ptr = lambda k: outs[k].data_ptr() if k in subset else None
         def step():
             ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["W3"].data_ptr(),
