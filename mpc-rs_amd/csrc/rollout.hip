@@ -88,7 +88,14 @@ int launch_lane_one(const RolloutArgs &a, hipStream_t s) {
 // next chunk are fetched into registers before the outputs of the current chunk are flushed from their LDS staging
 // area, so no load ever waits behind a store that was issued less than a chunk ago (loads and stores retire through
 // one in-order counter), and each flush writes runs of kChunk columns.
-constexpr int kChunk = 8;
+#ifndef MPCX_RO_CHUNK
+#define MPCX_RO_CHUNK 8
+#endif
+constexpr int kChunk = MPCX_RO_CHUNK;
+
+// LDS doubles per instance, kept even (16-byte aligned pairs).  (Staggering the instances of a wavefront over the LDS
+// banks by padding was measured: no gain, and the extra bytes cost resident wavefronts.)
+__host__ __device__ constexpr int pad_instance(int doubles) { return (doubles + 1) & ~1; }
 
 // HX / HY: X / Y is stored.  Every chunk issues exactly kChunk stores per output, whatever the lane, the group or the
 // step: lanes beyond the last row repeat row 0's store, groups beyond the batch repeat the last instance's stores and
@@ -99,9 +106,38 @@ constexpr int kChunk = 8;
 // shared input sequence and 168 (three waves) with per-instance inputs, which need prefetch registers.
 // SHU: one input sequence shared by every instance (simulator::step's unit input): it is read with wave-uniform loads
 // straight into the B u products, with no per-lane prefetch registers and no LDS staging.
-// FF: instance-major outputs with even n, r and 16-byte aligned bases: a chunk of X (kChunk n doubles) and of Y
-// (kChunk r doubles) is one contiguous run per instance, staged compactly in LDS and flushed as 16-byte pairs, the
-// group's lanes side by side (256-byte runs, kChunk NP / 32 store instructions per output instead of kChunk).
+// FF: instance-major outputs with even n, r and 16-byte aligned bases: a row of X or Y is one contiguous stream per
+// instance, staged in an LDS ring and flushed as 16-byte pairs, the group's lanes side by side (256-byte runs,
+// kChunk NP / 32 store instructions per output instead of kChunk).  Flushes end on the 128-byte line boundaries of
+// the row in memory (the remainder waits in the ring): runs that start or end inside a line cost a fifth of the
+// write rate (4.5 against 5.5 TB/s for this access shape, tools/stream_write.hip).
+// Orders the LDS traffic of ONE wavefront: the LDS executes a wavefront's instructions in issue order, so a value one
+// lane stores is what another lane of the same wavefront reads next without waiting for the store to complete; only the
+// compiler has to be kept from moving accesses across this point.  (A workgroup here is a single wavefront.)
+__device__ __forceinline__ void wave_lds_order() {
+#ifdef MPCX_RO_FULL_BARRIER
+    lds_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// One 16-byte pair of a row's stream, from the ring to memory, for the first and the last flush of a row: `a` is the
+// pair's aligned coordinate (even), `f` its unwrapped ring position (below 3 RS); entries outside [lo, hi) or at and
+// beyond the flush's end are not stored, and a pair with one live entry becomes an 8-byte store.
+__device__ __forceinline__ void flush_pair_masked(double *row, const double *ring, int a, int f, int RS, int lo, int hi, int end) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    f = f >= RS ? f - RS : f;
+    if (f >= RS) f -= RS;
+    const bool in0 = a >= lo && a < end && a < hi;
+    const bool in1 = a + 1 >= lo && a + 1 < end && a + 1 < hi;
+    if (in0 && in1) *(v2d *)(row + a) = *(const v2d *)(ring + f);
+    else if (in0) row[a] = ring[f];
+    else if (in1) row[a + 1] = ring[f + 1];
+}
+
 template <int G, int NP, int MB, bool HX, bool HY, bool SHU, bool FF>
 __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) void rollout_group_kernel(RolloutArgs p) {
     extern __shared__ double lds[];
@@ -114,9 +150,12 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
     const long long W = p.W, tile = b / W, li = b - tile * W, T = p.T;
 #define IN(ptr, E, e) ((ptr)[tile * (long long)(E) * W + (long long)(e) * W + li])
     // LDS per instance: [A | B | C when not in registers] x[2][G] u[kChunk][SU] out[kChunk][2][G]
-    constexpr int SU = (G <= 32) ? MB : G;  // inputs kept per step
+    constexpr int SU = (SHU && G <= 32) ? 0 : ((G <= 32) ? MB : G);  // inputs kept per step (none: shared inputs come through scalar loads)
     const int mats = kRegs ? 0 : n * n + n * m + r * n;
-    const int per_inst = mats + 2 * G + kChunk * SU + kChunk * 2 * G;
+    // staging of a chunk's outputs: two rings of RS doubles (X, Y) for the line-aligned paired flush, else [step][2][G]
+    constexpr int RS = kChunk * NP + 16;  // a full chunk plus the part of a line that waits for the next flush
+    const int stage = FF ? 2 * RS : kChunk * 2 * G;
+    const int per_inst = pad_instance(mats + 2 * G + kChunk * SU + stage);
     double *sA = lds + (size_t)g * per_inst, *sB = sA + (kRegs ? 0 : n * n), *sC = sB + (kRegs ? 0 : n * m);
     double *sx = sA + mats, *su = sx + 2 * G, *sOut = su + kChunk * SU;  // step q: [x_{t+1} (G) | y_t (G)]
     constexpr int RG = kRegs ? NP : 1, RB = kRegs ? MB : 1;
@@ -156,6 +195,20 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) pre[q] = ubase[(q < T ? q : T - 1) * ustep];
     }
+    // Paired flush: rows of X and Y as streams of doubles.  "Aligned coordinate" of a row = element index + mis, where
+    // mis is the row start's offset within its 128-byte line, so that multiples of 16 are line boundaries; rowx / rowy
+    // point at aligned coordinate 0 (a line start).  X's stream starts at element n (column 0 is stored above), Y's
+    // at 0.  Everything else (first unflushed line, ring positions) follows from the chunk's first step.
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    double *rowx = nullptr, *rowy = nullptr;
+    int misx = 0, misy = 0;
+    if constexpr (FF) {
+        double *bx = p.X ? p.X + b * EX : nullptr, *by = p.Y ? p.Y + b * EY : nullptr;
+        misx = (int)(((uintptr_t)bx >> 3) & 15);
+        misy = (int)(((uintptr_t)by >> 3) & 15);
+        rowx = bx - misx;
+        rowy = by - misy;
+    }
     lds_barrier();
     // One chunk.  The first chunk is peeled off the loop so that every entry to the loop body has the same history
     // (kChunk loads, then the chunk's stores): the wait on `pre` then only covers the loads.
@@ -167,6 +220,9 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
 #endif
     auto chunk = [&](const long long t0) {
         const int steps = (int)((T - t0 < kChunk) ? T - t0 : kChunk);
+        // (FF) aligned coordinates of the first entries this chunk produces, and their ring positions
+        const int prodx = ((int)t0 + 1) * n + misx, prody = (int)t0 * r + misy;
+        const int wx = prodx % RS, wy = prody % RS;
         RSTAMP(0);
         if constexpr (!SHU) {
 #pragma unroll
@@ -218,16 +274,21 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
             if constexpr (kRegs) {
                 // all state reads go out before the first multiply-add: one LDS latency per step, not one per pair
                 double xr[NP];
+                typedef double v2d __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int j = 0; j < NP; ++j) xr[j] = xc[j];
+                for (int j = 0; j < NP; j += 2) {  // 16-byte reads: half the LDS cycles of paired 8-byte reads
+                    const v2d pr = *(const v2d *)(xc + j);
+                    xr[j] = pr.x;
+                    xr[j + 1] = pr.y;
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // two partial sums per dot product: four independent multiply-add chains instead of two
                 double s1 = 0.0, y1 = 0.0;
 #pragma unroll
                 for (int j = 0; j < NP; j += 2) {
                     s += rA[j] * xr[j];
-                    y += rC[j] * xr[j];
                     s1 += rA[j + 1] * xr[j + 1];
+                    y += rC[j] * xr[j];
                     y1 += rC[j + 1] * xr[j + 1];
                 }
                 s += s1;
@@ -247,25 +308,59 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
             // rows at and beyond n (r) carry zero coefficients, so every lane writes: no divergence inside the step
             xn[i] = s;
             if constexpr (FF) {
-                if (i < n) sOut[q * n + i] = s;
-                if (i < r) sOut[kChunk * G + q * r + i] = y;
+                // ring position of this step's entries (a single wrap: the offsets stay below the ring size)
+                int px = wx + q * n + i, py = wy + q * r + i;
+                px = px >= RS ? px - RS : px;
+                py = py >= RS ? py - RS : py;
+                if (i < n) sOut[px] = s;
+                if (i < r) sOut[RS + py] = y;
             } else {
                 out[i] = s;
                 out[G + i] = y;
             }
-            lds_barrier();
+            wave_lds_order();
         }
         RSTAMP(3);
         if constexpr (FF) {
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            constexpr int NST = (kChunk * NP + 2 * G - 1) / (2 * G);  // pair stores per lane and output
-            const int lastx = steps * n / 2 - 1, lasty = steps * r / 2 - 1;  // last pair of this chunk (n, r even)
-            double *gx = p.X + b * EX + (t0 + 1) * n, *gy = p.Y + b * EY + t0 * r;
+            // Flush up to the last 128-byte line boundary of each row that the chunk has reached; what lies beyond it
+            // (less than a line) stays in the ring for the next chunk.  A full chunk advances a row by kChunk n doubles,
+            // a whole number of lines (n is even), so between the first and the last chunk every flush is the same
+            // number of whole lines.  The first flush starts inside a line (a row starts wherever the previous one ended)
+            // and the last one ends inside one: those two mask by element.
+            const bool last = t0 + steps >= T;
+            const bool edge = last || t0 == 0;  // wave-uniform
+            const int ax = prodx & ~15, ay = prody & ~15;  // first unflushed line of each row
+            const int fx = ax % RS, fy = ay % RS;
+            if (edge) {
+                constexpr int NSTE = (kChunk * NP + 16 + 2 * G - 1) / (2 * G);  // one more line than a full chunk
+                const int endx = (int)EX + misx, endy = (int)EY + misy;
+                const int ax_new = last ? ((endx + 15) & ~15) : ((prodx + steps * n) & ~15);
+                const int ay_new = last ? ((endy + 15) & ~15) : ((prody + steps * r) & ~15);
 #pragma unroll
-            for (int k = 0; k < NST; ++k) {
-                const int e = i + k * G;
-                if (HX) { const int ex = e < lastx ? e : lastx; *(v2d *)(gx + 2 * ex) = *(const v2d *)(sOut + 2 * ex); }
-                if (HY) { const int ey = e < lasty ? e : lasty; *(v2d *)(gy + 2 * ey) = *(const v2d *)(sOut + kChunk * G + 2 * ey); }
+                for (int k = 0; k < NSTE; ++k) {
+                    const int e2 = 2 * (i + k * G);  // offset of this lane's pair from the first unflushed line
+                    if (HX) flush_pair_masked(rowx, sOut, ax + e2, fx + e2, RS, n + misx, last ? endx : ax_new, ax_new);
+                    if (HY) flush_pair_masked(rowy, sOut + RS, ay + e2, fy + e2, RS, misy, last ? endy : ay_new, ay_new);
+                }
+            } else {
+                constexpr int NST = (kChunk * NP + 2 * G - 1) / (2 * G);  // pair stores per lane and output
+                // every ring read first, then the stores: one LDS latency per flush instead of one per store
+                v2d vx[NST], vy[NST];
+#pragma unroll
+                for (int k = 0; k < NST; ++k) {
+                    const int e2 = 2 * (i + k * G);
+                    int f = fx + e2, h = fy + e2;
+                    f = f >= RS ? f - RS : f;
+                    h = h >= RS ? h - RS : h;
+                    if (HX) vx[k] = *(const v2d *)(sOut + (e2 < kChunk * n ? f : 0));
+                    if (HY) vy[k] = *(const v2d *)(sOut + RS + (e2 < kChunk * r ? h : 0));
+                }
+#pragma unroll
+                for (int k = 0; k < NST; ++k) {
+                    const int e2 = 2 * (i + k * G);
+                    if (HX && e2 < kChunk * n) *(v2d *)(rowx + ax + e2) = vx[k];
+                    if (HY && e2 < kChunk * r) *(v2d *)(rowy + ay + e2) = vy[k];
+                }
             }
         } else {
 #pragma unroll
@@ -297,7 +392,9 @@ int launch_group_inst(const RolloutArgs &a, hipStream_t s) {
     const long long blocks = (a.batch + IPW - 1) / IPW;
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     const size_t mats = G <= 32 ? 0 : (size_t)a.n * a.n + (size_t)a.n * a.m + (size_t)a.r * a.n;
-    const size_t per_inst = mats + 2 * G + (size_t)kChunk * (G <= 32 ? MB : G) + (size_t)kChunk * 2 * G;
+    const size_t su = (SHU && G <= 32) ? 0 : (G <= 32 ? MB : G);
+    const size_t stage = FF ? (size_t)2 * (kChunk * NP + 16) : (size_t)kChunk * 2 * G;
+    const size_t per_inst = (size_t)pad_instance((int)(mats + 2 * G + (size_t)kChunk * su + stage));
     const size_t lds_bytes = per_inst * IPW * sizeof(double);
     if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
     if (lds_bytes > 64 * 1024) {
@@ -312,7 +409,9 @@ int launch_group_inst(const RolloutArgs &a, hipStream_t s) {
 template <int G, int NP, int MB>
 int launch_group_np(const RolloutArgs &a, hipStream_t s) {
     if constexpr (G <= 32) {
-        const bool ff = a.W == 1 && a.n % 2 == 0 && a.r % 2 == 0 && (((uintptr_t)a.X | (uintptr_t)a.Y) & 15) == 0;
+        // (the paired flush indexes a row with 32-bit offsets)
+        const bool short_rows = (long long)(a.n > a.r ? a.n : a.r) * (a.T + 2) < 0x7fffff00LL;
+        const bool ff = a.W == 1 && a.n % 2 == 0 && a.r % 2 == 0 && (((uintptr_t)a.X | (uintptr_t)a.Y) & 15) == 0 && short_rows;
         if (a.u_shared && ff) {
             if (a.X && a.Y) return launch_group_inst<G, NP, MB, true, true, true, true>(a, s);
             if (a.X) return launch_group_inst<G, NP, MB, true, false, true, true>(a, s);
