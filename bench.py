@@ -382,16 +382,17 @@ def main():
             res["lib_gather"] = lib_gather
         if mfma_ms is not None:
             # The contraction kernel against the FP64 matrix-core peak.  `frac` counts the flops the kernel EXECUTES:
-            # one v_mfma_f64_16x16x4_f64 is 2048 flops and the kernel issues a fixed number of them per instance
-            # (mfma_insts_per_unit, confirmed by the SQ_INSTS_VALU_MFMA_F64 counter pass recorded under profiles/).
+            # one v_mfma_f64_16x16x4_f64 is 2048 flops and the kernel issues a number of them that depends on the shape
+            # only (_mfma_insts, checked against the SQ_INSTS_VALU_MFMA_F64 counter pass recorded under profiles/).
             # The algorithmic rate (symmetric count, block-diagonal weight) is a side field: it exceeds what ran only
             # on paper, because the dense contraction also multiplies structural zeros.
-            insts = _mfma_insts(args.workload, per_gpu, f, v)
+            symmetric = bool(np.array_equal(case.d["W3"], case.d["W3"].T) and np.array_equal(case.d["Q"], case.d["Q"].T))
+            insts = _mfma_insts(m, r, f, v, per_gpu, symmetric)
             fl_alg = flops_h(m, r, f, v) * per_gpu / (mfma_ms * 1e-3)
             fl_exec = (insts * 2048.0 / (mfma_ms * 1e-3)) if insts else None
             res["roofline"] = {"bound": "mfma", "achieved": (fl_exec or 0.0) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
                                "frac": (fl_exec / FP64_PEAK) if fl_exec else None, "traffic": None, "kernel_ms": mfma_ms,
-                               "kernel": "hessian_mfma_kernel", "mfma_insts_per_launch": insts,
+                               "kernel": "hessian_mfma_kernel", "mfma_insts_per_launch": insts, "symmetric_tiles_skipped": symmetric,
                                "algorithmic_TFLOP_per_s": fl_alg / 1e12, "algorithmic_frac": fl_alg / FP64_PEAK,
                                "flops_per_unit": flops_h(m, r, f, v),
                                "dense_flops_per_unit": 2 * f * r * (v * m) ** 2, "step_ms_all_kernels": kernel_ms,
@@ -441,16 +442,21 @@ ALSO = (("msd", "qp", 0, 0), ("quadrotor", "qp", 0, 0), ("long", "qp", 0, 0),
         ("msd", "rollout", 0, 0), ("two_mass", "rollout", 0, 0), ("quadrotor", "rollout", 0, 0))
 
 
-def _mfma_insts(workload, per_gpu, f, v):
-    """v_mfma_f64_16x16x4_f64 instructions one launch of the contraction kernel issues, from the counter pass recorded
-    under profiles/ (SQ_INSTS_VALU_MFMA_F64; the count is a function of the shape only)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh).get(f"mfma:{workload}:{per_gpu}:{f}:{v}")
-        return rec["mfma_insts_per_launch"] if rec else None
-    except (OSError, ValueError, KeyError):
-        return None
+def _mfma_insts(m, r, f, v, per_gpu, symmetric=False):
+    """v_mfma_f64_16x16x4_f64 instructions one launch of the contraction kernel issues: a wavefront owns a 48 x 48 tile
+    of H as 3 x 3 accumulators and walks the contraction index in steps of 4 from the first row where both operand tiles
+    can be non-zero (hessian_mfma.hip); with Q and W3 exactly symmetric only the tiles on and below the diagonal are
+    computed.  The count depends on the shape only; the SQ_INSTS_VALU_MFMA_F64 counter passes under profiles/
+    (186,753,024 for n=8 m=2 r=2 f=v=400, batch 1024, all tiles) are what this formula was checked against."""
+    FR, VM, kT = f * r, v * m, 48
+    nt = (VM + kT - 1) // kT
+    total = 0
+    for ta in range(nt):
+        for tb in range(ta + 1 if symmetric else nt):
+            sa, sb = (ta * kT // m) * r, (tb * kT // m) * r
+            kstart = max(sa, sb) & ~3
+            total += 9 * ((FR - kstart + 3) // 4)
+    return total * per_gpu
 
 
 def _traffic(op, workload, per_gpu, f=0, v=0):

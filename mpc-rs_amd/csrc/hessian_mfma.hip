@@ -18,10 +18,11 @@ namespace mpcx {
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kTrLd = 17;  // leading dimension of the transpose scratch (odd: conflict-free both ways)
 using d4 = __attribute__((ext_vector_type(4))) double;
 
 struct MfLds {
-    int A, B, C, Q, W, G, S, QG, QS, total;  // offsets in doubles
+    int A, B, C, Q, W, G, S, QG, QS, Tr, total;  // offsets in doubles
 };
 
 __host__ __device__ inline MfLds mf_lds_layout(int n, int m, int r, int f, int v) {
@@ -37,6 +38,7 @@ __host__ __device__ inline MfLds mf_lds_layout(int n, int m, int r, int f, int v
     L.S = o; o += m * nl * r;   // cumulated blocks of the held-input column
     L.QG = o; o += m * fr;      // Q G_k
     L.QS = o; o += m * nl * r;  // Q S_j
+    L.Tr = o; o += (kThreads / 64) * kTrLd * 16;  // one 16 x 16 block per wavefront (mirrored stores of a symmetric H)
     L.total = o;
     return L;
 }
@@ -68,6 +70,22 @@ __device__ inline double col_at(const ColRef &c, int rho, int FR) {
     return ok ? x : 0.0;
 }
 
+// *flag (set to 1 by the caller) is cleared when Q (r x r) or W3 (vm x vm) is not exactly symmetric.
+__global__ __launch_bounds__(256) void symmetry_kernel(const double *__restrict__ Q, int r, const double *__restrict__ W3, int vm,
+                                                       int *flag) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, nq = (long long)r * r, nw = (long long)vm * vm;
+    bool bad = false;
+    if (idx < nq) {
+        const int i = (int)(idx % r), j = (int)(idx / r);
+        bad = i < j && !(Q[idx] == Q[(long long)i * r + j]);
+    } else if (idx < nq + nw) {
+        const long long e = idx - nq;
+        const int i = (int)(e % vm), j = (int)(e / vm);
+        bad = i < j && !(W3[e] == W3[(long long)i * vm + j]);
+    }
+    if (bad) *flag = 0;
+}
+
 __global__ __launch_bounds__(kThreads) void hessian_mfma_kernel(QpArgs p) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
@@ -77,6 +95,9 @@ __global__ __launch_bounds__(kThreads) void hessian_mfma_kernel(QpArgs p) {
     const MfLds L = mf_lds_layout(n, m, r, f, v);
     double *sA = lds + L.A, *sB = lds + L.B, *sC = lds + L.C, *sQ = lds + L.Q, *sW = lds + L.W;
     double *sG = lds + L.G, *sS = lds + L.S, *sQG = lds + L.QG, *sQS = lds + L.QS;
+    // Q and W3 symmetric (measured on the device by the launcher): H is symmetric, only the tiles on and below the
+    // diagonal are computed and the others are their mirror images
+    const bool sym = p.w3win != nullptr && ((const int *)p.w3win)[2] != 0;
 
     const double *gA = p.A + b * (long long)(n * n);
     const double *gB = p.B + b * (long long)(n * m);
@@ -135,8 +156,19 @@ __global__ __launch_bounds__(kThreads) void hessian_mfma_kernel(QpArgs p) {
     const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int nt = (VM + kT - 1) / kT;
     double *gH = p.H + b * (long long)VM * VM;
-    for (int tile = wave; tile < nt * nt; tile += kThreads / 64) {
-        const int tb = tile / nt, ta = tile - tb * nt;  // consecutive waves walk down a column of tiles
+    double *sTr = lds + L.Tr + wave * (kTrLd * 16);
+    const int ntiles = sym ? nt * (nt + 1) / 2 : nt * nt;
+    for (int tile = wave; tile < ntiles; tile += kThreads / 64) {
+        int ta, tb;
+        if (sym) {  // tile = ta (ta + 1) / 2 + tb with tb <= ta
+            ta = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+            while (ta * (ta + 1) / 2 > tile) --ta;
+            while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
+            tb = tile - ta * (ta + 1) / 2;
+        } else {
+            tb = tile / nt;  // consecutive waves walk down a column of tiles
+            ta = tile - tb * nt;
+        }
         const int a0 = ta * kT, b0 = tb * kT;
         // A operand rows = columns b0.. of T, B operand columns = columns a0.. of Gamma (transposed product)
         ColRef tcol[kU], gcol[kU];
@@ -148,23 +180,67 @@ __global__ __launch_bounds__(kThreads) void hessian_mfma_kernel(QpArgs p) {
         // first row where both operand tiles can be non-zero: the larger of the two tiles' smallest shifts
         const int sa = (a0 / m) * r, sb = (b0 / m) * r;
         const int kstart = (sa > sb ? sa : sb) & ~3;
+        // The accumulators start from this tile's share of W3 (H = Gamma^T W4 Gamma + W3): its loads are in flight during
+        // the first contraction steps instead of standing between the last one and the stores.
         d4 acc[kU][kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u)
 #pragma unroll
-            for (int w = 0; w < kU; ++w) acc[u][w] = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int rho0 = kstart; rho0 < FR; rho0 += 4) {
-            const int rho = rho0 + kq;
-            double av[kU], bv[kU];
+            for (int w = 0; w < kU; ++w) {
+                const int row = a0 + 16 * w + l15;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int col = b0 + 16 * u + kq + 4 * reg;
+                    acc[u][w][reg] = (row < VM && col < VM) ? p.W3[(long long)col * VM + row] : 0.0;
+                }
+            }
+        // Three stretches of the contraction index.  Up to the row where the last column of either operand tile has
+        // started (kfull) an operand may still be a structural zero: masked reads.  From there to the last whole step
+        // every operand is a plain element of its vector: one LDS read at pointer + rho, no compare, no select (the
+        // index arithmetic of the masked form costs more issue slots than the matrix instructions it feeds).  A tile
+        // that hangs over the edge of H (columns >= v m) stays masked throughout.
+        auto masked_steps = [&](int from, int to) {
+            for (int rho0 = from; rho0 < to; rho0 += 4) {
+                const int rho = rho0 + kq;
+                double av[kU], bv[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    av[u] = col_at(tcol[u], rho, FR);
+                    bv[u] = col_at(gcol[u], rho, FR);
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u)
+#pragma unroll
+                    for (int w = 0; w < kU; ++w) acc[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[w], acc[u][w], 0, 0, 0);
+            }
+        };
+        const bool inside = (a0 + kT <= VM) && (b0 + kT <= VM);
+        const int lasta = ((a0 + kT - 1) / m) * r, lastb = ((b0 + kT - 1) / m) * r;  // shifts of the tiles' last columns
+        int kfull = ((lasta > lastb ? lasta : lastb) + 3) & ~3;
+        const int kwhole = FR & ~3;
+        if (!inside || kfull > kwhole) kfull = FR;  // all masked
+        masked_steps(kstart, kfull < FR ? kfull : FR);
+        if (kfull < kwhole) {
+            const double *pa[kU], *pb[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                av[u] = col_at(tcol[u], rho, FR);
-                bv[u] = col_at(gcol[u], rho, FR);
+                pa[u] = tcol[u].base - tcol[u].shift + kq;
+                pb[u] = gcol[u].base - gcol[u].shift + kq;
             }
+#pragma unroll 2
+            for (int rho0 = kfull; rho0 < kwhole; rho0 += 4) {
+                double av[kU], bv[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u)
+                for (int u = 0; u < kU; ++u) {
+                    av[u] = pa[u][rho0];
+                    bv[u] = pb[u][rho0];
+                }
 #pragma unroll
-                for (int w = 0; w < kU; ++w) acc[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[w], acc[u][w], 0, 0, 0);
+                for (int u = 0; u < kU; ++u)
+#pragma unroll
+                    for (int w = 0; w < kU; ++w) acc[u][w] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[w], acc[u][w], 0, 0, 0);
+            }
+            masked_steps(kwhole, FR);
         }
         // D[i][j] = H[a0 + 16 w + j][b0 + 16 u + i]; lane holds j = l15 and i = kq + 4 reg
 #pragma unroll
@@ -175,10 +251,26 @@ __global__ __launch_bounds__(kThreads) void hessian_mfma_kernel(QpArgs p) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int col = b0 + 16 * u + kq + 4 * reg;
-                    if (row < VM && col < VM) {
-                        const long long e = (long long)col * VM + row;
-                        gH[e] = acc[u][w][reg] + p.W3[e];
+                    if (row < VM && col < VM) gH[(long long)col * VM + row] = acc[u][w][reg];
+                }
+                if (sym && ta != tb) {
+                    // the mirror image H[col][row]: the block goes through LDS so that the 16 lanes that share a register
+                    // hold 16 consecutive rows of the mirrored column again (128-byte runs)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) sTr[l15 * kTrLd + kq + 4 * reg] = acc[u][w][reg];  // [j][i]
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int mrow = b0 + 16 * u + l15;  // = col index of the original
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int jj = kq + 4 * reg, mcol = a0 + 16 * w + jj;
+                        const double x = sTr[jj * kTrLd + l15];
+                        if (mrow < VM && mcol < VM) gH[(long long)mcol * VM + mrow] = x;
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
     }
@@ -199,7 +291,19 @@ int launch_hessian_mfma(const QpArgs &a, hipStream_t s) {
                                            (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(hessian_mfma_kernel, dim3((unsigned)a.batch), dim3(kThreads), lds_bytes, s, a);
+    QpArgs b = a;
+    if (a.w3win && a.w3win_bytes >= 3 * sizeof(int)) {
+        int *flag = (int *)a.w3win + 2;
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)flag, 1, 1, s);
+        if (e != hipSuccess) return (int)e;
+        const long long cells = (long long)a.r * a.r + (long long)a.v * a.m * a.v * a.m;
+        hipLaunchKernelGGL(symmetry_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, a.W4, a.r, a.W3, a.v * a.m, flag);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    } else {
+        b.w3win = nullptr;
+    }
+    hipLaunchKernelGGL(hessian_mfma_kernel, dim3((unsigned)a.batch), dim3(kThreads), lds_bytes, s, b);
     return (int)hipGetLastError();
 }
 

@@ -199,6 +199,17 @@ def test_hessian_contraction_on_matrix_cores(ctx, n, m, r, f, v):
     assert np.array_equal(only_h["H"], got["H"])
     structured = _run(ctx, data, 1, want=("H",), hessian_algo=ffi.HESSIAN_STRUCTURED)
     assert_close(structured["H"], got["H"], "structured vs contraction")
+    # exactly symmetric weights: the kernel computes the tiles on and below the diagonal only and mirrors the rest
+    sym = dict(data, W3=data["W3"] + data["W3"].T, Q=data["Q"] + data["Q"].T)
+    want_s = oracle_qp(orc, sym, want=("H",))
+    got_s = _run(ctx, sym, 1, want=("H",), hessian_algo=ffi.HESSIAN_CONTRACT)
+    assert_close(got_s["H"], want_s["H"], f"contract, symmetric weights n{n} m{m} r{r} f{f} v{v}")
+    if v * m > 48:  # tiles off the diagonal (48 x 48) are exact copies of their mirror images
+        assert np.array_equal(got_s["H"][:, 48:, :48], got_s["H"][:, :48, 48:].transpose(0, 2, 1))
+    # one weight symmetric, the other not: no mirroring
+    half = dict(data, W3=sym["W3"])
+    assert_close(_run(ctx, half, 1, want=("H",), hessian_algo=ffi.HESSIAN_CONTRACT)["H"], oracle_qp(orc, half, want=("H",))["H"],
+                 "contract, only W3 symmetric")
 
 
 @pytest.mark.parametrize("interleave", [0, 64, 128])
