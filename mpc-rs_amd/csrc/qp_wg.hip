@@ -150,52 +150,52 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
     const int koff = dd * r, kend = koff + (bg ? K - r : K);    // this column is non-zero for koff <= k' < kend
     const double *b1 = (bg ? sQG + jb * FR : sQS + jb * K) - koff;
     const double *b2 = (bg ? sG + jb * FR : sS + jb * K) - koff;
-    for (int tile = wave; tile < nt; tile += nwaves) {
+    // work item = (tile of 16 operand rows, which of the two products): no two items share an operand read
+    for (int item = wave; item < 2 * nt; item += nwaves) {
+        const int tile = item >> 1;
+        const bool second = item & 1;  // Z2: Hankel operand from Q G, right operand [G | S]
         const int R = tile * 16 + l15;
         const bool rowok = R < rows;
         const int dq = rowok ? R / m : 0, c = rowok ? R - dq * m : 0;
         const bool srow = (dq == NQ);
-        const double *a1 = srow ? sS + c * K : sG + c * FR + dq * ND * r;
-        const double *a2 = srow ? sQS + c * K : sQG + c * FR + dq * ND * r;
+        const double *pa = second ? (srow ? sQS + c * K : sQG + c * FR + dq * ND * r) : (srow ? sS + c * K : sG + c * FR + dq * ND * r);
+        const double *pb = second ? b2 : b1;
         const int klim = srow ? K : Kx;  // (rows whose d runs past v-1 read on into the next vector: finite, discarded)
         // where this lane's four results go: memory (with W3, read now and used after the contraction) or the border
-        double w3a[4], w3b[4];
-        long long ea[4], eb[4];
+        double w3v[4];
+        long long eg[4];
         int ta[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int Ri = tile * 16 + kq + 4 * reg;
             const int dqi = Ri / m, ci = Ri - dqi * m, di = dqi * ND + dd;
-            ea[reg] = eb[reg] = -1;
+            eg[reg] = -1;
             ta[reg] = -1;
             if (Ri < rows && bok) {
                 if (dqi == NQ) {
-                    if (dd == 0 && !bg) ea[reg] = (long long)((v - 1) * m + jb) * VM + (v - 1) * m + ci;  // corner
+                    if (dd == 0 && !bg && !second) eg[reg] = (long long)((v - 1) * m + jb) * VM + (v - 1) * m + ci;  // corner
                 } else if (di < v) {
                     if (bg) ta[reg] = v - di;  // a' resp. b'
-                    else if (di > 0) {
-                        ea[reg] = (long long)((v - 1) * m + jb) * VM + (v - 1 - di) * m + ci;  // H[a][v-1][ci][jb]
-                        eb[reg] = (long long)((v - 1 - di) * m + ci) * VM + (v - 1) * m + jb;  // H[v-1][b][jb][ci]
-                    }
+                    else if (di > 0)
+                        eg[reg] = second ? (long long)((v - 1 - di) * m + ci) * VM + (v - 1) * m + jb   // H[v-1][b][jb][ci]
+                                         : (long long)((v - 1) * m + jb) * VM + (v - 1 - di) * m + ci;  // H[a][v-1][ci][jb]
                 }
             }
-            w3a[reg] = ea[reg] >= 0 ? gW3[ea[reg]] : 0.0;
-            w3b[reg] = eb[reg] >= 0 ? gW3[eb[reg]] : 0.0;
+            w3v[reg] = eg[reg] >= 0 ? gW3[eg[reg]] : 0.0;
         }
-        d4 acc1 = (d4){0.0, 0.0, 0.0, 0.0}, acc2 = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int k0 = 0; k0 < Kx; k0 += 8) {  // two steps of four per round: the eight LDS reads are in flight together
-            const int ka = k0 + kq, kb = k0 + 4 + kq;
-            const bool ra = rowok && ka < klim, rb = rowok && kb < klim;
-            const bool ca = bok && ka >= koff && ka < kend, cb = bok && kb >= koff && kb < kend;
-            const int ia = ra ? ka : 0, ib = rb ? kb : 0, ja = ca ? ka : koff, jbk = cb ? kb : koff;
-            double x1a = a1[ia], y1a = b1[ja], x2a = a2[ia], y2a = b2[ja];
-            double x1b = a1[ib], y1b = b1[jbk], x2b = a2[ib], y2b = b2[jbk];
-            x1a = ra ? x1a : 0.0; x2a = ra ? x2a : 0.0; y1a = ca ? y1a : 0.0; y2a = ca ? y2a : 0.0;
-            x1b = rb ? x1b : 0.0; x2b = rb ? x2b : 0.0; y1b = cb ? y1b : 0.0; y2b = cb ? y2b : 0.0;
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1a, y1a, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2a, y2a, acc2, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1b, y1b, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2b, y2b, acc2, 0, 0, 0);
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < Kx; k0 += 16) {  // four steps of four per round: the eight LDS reads are in flight together
+            double x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k0 + 4 * u + kq;
+                const bool rk = rowok && kk < klim, ck = bok && kk >= koff && kk < kend;
+                const double xv = pa[rk ? kk : 0], yv = pb[ck ? kk : koff];
+                x[u] = rk ? xv : 0.0;
+                y[u] = ck ? yv : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], acc, 0, 0, 0);
         }
         // D[i][j]: this lane holds column j = l15 and rows i = kq + 4 reg of the tile
 #pragma unroll
@@ -203,11 +203,10 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
             const int Ri = tile * 16 + kq + 4 * reg;
             const int ci = Ri % m;
             if (ta[reg] >= 0) {
-                vcol[(ci * m + jb) * ldh + ta[reg]] = acc1[reg];  // Ht[a'][v][ci][jb]
-                vrow[(jb * m + ci) * ldh + ta[reg]] = acc2[reg];  // Ht[v][b'][jb][ci]
+                if (second) vrow[(jb * m + ci) * ldh + ta[reg]] = acc[reg];  // Ht[v][b'][jb][ci]
+                else vcol[(ci * m + jb) * ldh + ta[reg]] = acc[reg];         // Ht[a'][v][ci][jb]
             }
-            if (ea[reg] >= 0) gH[ea[reg]] = acc1[reg] + w3a[reg];
-            if (eb[reg] >= 0) gH[eb[reg]] = acc2[reg] + w3b[reg];
+            if (eg[reg] >= 0) gH[eg[reg]] = acc[reg] + w3v[reg];
         }
     }
 }

@@ -539,6 +539,35 @@ void orc_closed_loop(const double *A, const double *B, const double *C, int n, i
     free(u);
 }
 
+/* The same loop for any m, r (the reference handles m = r = 1 only: controller.rs:119-122 slices a T x 1 trajectory and
+ * :131-132 takes element (0,0)): the window is stacked time-major, vec_s[i r + a] = ref[a][t + i] - (O x)[i r + a]
+ * (:125-127), u = the first m entries of gain * vec_s (:130), then propagate_dynamics (:106-112).  Same products, same
+ * order of operations as orc_compute_control_input / orc_propagate_dynamics.  ref is r x (steps + f), column-major;
+ * X is n x (steps + 1), U m x steps, Y r x steps (Y[:, t] = C x_t). */
+void orc_closed_loop_mimo(const double *A, const double *B, const double *C, int n, int m, int r, int f, int v,
+                          const double *O, const double *gain, const double *ref, int steps, const double *x0, double *X,
+                          double *U, double *Y) {
+    mat mat_o = mat_from(O, f * r, n), g = mat_from(gain, v * m, f * r);
+    memcpy(X, x0, sizeof(double) * (size_t)n);
+    for (int t = 0; t < steps; ++t) {
+        const double *x = X + (size_t)t * n;
+        mat xs = mat_from(x, n, 1);
+        mat ox = mat_mul(&mat_o, &xs);
+        mat vec_s = mat_zeros(f * r, 1);
+        for (int i = 0; i < f; ++i)
+            for (int a = 0; a < r; ++a) vec_s.d[i * r + a] = ref[(size_t)(t + i) * r + a] - ox.d[i * r + a];
+        mat seq = mat_mul(&g, &vec_s);
+        for (int k = 0; k < m; ++k) U[(size_t)t * m + k] = seq.d[k];
+        orc_propagate_dynamics(A, B, C, n, m, r, U + (size_t)t * m, x, X + (size_t)(t + 1) * n, Y + (size_t)t * r);
+        mat_free(&xs);
+        mat_free(&ox);
+        mat_free(&vec_s);
+        mat_free(&seq);
+    }
+    mat_free(&mat_o);
+    mat_free(&g);
+}
+
 /* ---------------------------------------------------------------------------------------------------
  * Batch drivers (instance-major buffers): the per-instance functions above, unchanged, in a loop.
  * ------------------------------------------------------------------------------------------------- */

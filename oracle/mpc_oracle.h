@@ -86,6 +86,10 @@ int orc_pulse_trajectory(int time_steps, double *traj);
 void orc_closed_loop(const double *A, const double *B, const double *C, int n, int m, int r, int f, int v,
                      const double *O, const double *gain, const double *traj_total, int steps, const double *x0,
                      double *states, double *outputs, double *inputs);
+/* The loop for any m, r (window stacked time-major; the reference itself is SISO): ref r x (steps + f) column-major. */
+void orc_closed_loop_mimo(const double *A, const double *B, const double *C, int n, int m, int r, int f, int v,
+                          const double *O, const double *gain, const double *ref, int steps, const double *x0, double *X,
+                          double *U, double *Y);
 
 /* try_inverse as nalgebra does it (closed forms up to 4x4, LU with partial pivoting above).
  * a is n x n, overwritten with its inverse; returns 0 on failure. */

@@ -53,6 +53,8 @@ def lib(variant: str = "") -> C.CDLL:
     L.orc_pulse_trajectory.restype = i
     L.orc_closed_loop.argtypes = [_P, _P, _P, i, i, i, i, i, _P, _P, _P, i, _P, _P, _P, _P]
     L.orc_closed_loop.restype = None
+    L.orc_closed_loop_mimo.argtypes = [_P, _P, _P, i, i, i, i, i, _P, _P, _P, i, _P, _P, _P, _P]
+    L.orc_closed_loop_mimo.restype = None
     L.orc_try_inverse.argtypes = [_P, i]
     L.orc_try_inverse.restype = i
     L.orc_qp_build_batch.argtypes = [i64, i, i, i, i, i, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, i]
@@ -169,6 +171,21 @@ def closed_loop(A, B, Cm, f, v, O, gain, traj_total, steps, x0, variant=""):
     lib(variant).orc_closed_loop(_p(a_), _p(b_), _p(c_), n, m, r, f, v, _p(o_), _p(g_), _p(t_), steps, _p(x_),
                                  _p(states), _p(outputs), _p(inputs))
     return _from_cm(states, n, steps + 1), _from_cm(outputs, r, steps + 1), inputs[:steps]
+
+
+def closed_loop_mimo(A, B, Cm, f, v, O, gain, ref, steps, x0, variant=""):
+    """ref (r, steps + f).  Returns X (n, steps+1), U (m, steps), Y (r, steps)."""
+    A, B, Cm = (np.asarray(q, dtype=np.float64) for q in (A, B, Cm))
+    n, m, r = A.shape[0], B.shape[1], Cm.shape[0]
+    X, U, Y = np.zeros(n * (steps + 1)), np.zeros(max(m * steps, 1)), np.zeros(max(r * steps, 1))
+    a_, b_, c_, o_, g_ = _cm(A), _cm(B), _cm(Cm), _cm(O), _cm(gain)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert ref.shape == (r, steps + f)
+    r_ = _cm(ref)
+    x_ = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(-1))
+    lib(variant).orc_closed_loop_mimo(_p(a_), _p(b_), _p(c_), n, m, r, f, v, _p(o_), _p(g_), _p(r_), steps, _p(x_),
+                                      _p(X), _p(U), _p(Y))
+    return _from_cm(X, n, steps + 1), _from_cm(U[:m * steps], m, steps), _from_cm(Y[:r * steps], r, steps)
 
 
 def try_inverse(a, variant=""):

@@ -1,5 +1,6 @@
 """GPU parity of the batched receding-horizon loop (reference: src/main.rs:51-71 over controller.rs:101-135) against
-the oracle (m = r = 1, the only case the reference handles) and a numpy restatement of the same formulas for m, r > 1.
+the oracle: orc_closed_loop for m = r = 1, the only case the reference handles, and orc_closed_loop_mimo (the same
+products with the window stacked time-major) for m, r > 1.
 Tolerance: relative Frobenius error <= 1e-10 on states, inputs and outputs, given the same Phi and gain."""
 import json
 import os
@@ -75,7 +76,7 @@ def test_siso_against_oracle(ctx, name, batch, il, T, f, v, shared):
     (2, 1, 1, 20, 20, 3, 1, False),     # T < chunk
     (9, 3, 3, 5, 5, 0, 1, False),       # T = 0
 ])
-def test_mimo_against_numpy(ctx, n, m, r, f, v, T, il, shared):
+def test_mimo_against_oracle(ctx, n, m, r, f, v, T, il, shared):
     rng = np.random.default_rng(n * 100 + m * 10 + r)
     batch = 23
     A, B, C = random_stable_plants(rng, batch, n, m, r)
@@ -84,7 +85,12 @@ def test_mimo_against_numpy(ctx, n, m, r, f, v, T, il, shared):
     gain = rng.standard_normal((batch, v * m, f * r)) * (0.2 / np.sqrt(f * r))
     ref = rng.uniform(0, 1, (r, T + f)) if shared else rng.uniform(0, 1, (batch, r, T + f))
     got = ctx.closed_loop(A, B, C, x0, Phi, gain, ref, T, f, v, interleave=il)
-    want = [np_closed_loop(A[b], B[b], C[b], x0[b], Phi[b], gain[b], ref if shared else ref[b], T, f) for b in range(batch)]
+    # the C oracle's loop for any m, r (orc_closed_loop_mimo: the products and order of compute_control_input and
+    # propagate_dynamics); the numpy restatement above must agree with it
+    want = [orc.closed_loop_mimo(A[b], B[b], C[b], f, v, Phi[b], gain[b], ref if shared else ref[b], T, x0[b]) for b in range(batch)]
+    for b in (0, batch - 1):
+        for w, q in zip(want[b], np_closed_loop(A[b], B[b], C[b], x0[b], Phi[b], gain[b], ref if shared else ref[b], T, f)):
+            assert np.allclose(w, q, rtol=1e-11, atol=1e-13)
     assert got["X"].shape == (batch, n, T + 1)
     assert_close(got["X"], np.stack([w[0] for w in want]), "states")
     if T:
