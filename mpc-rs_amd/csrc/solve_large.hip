@@ -16,8 +16,16 @@
 //      panel's unit lower triangle) and subtracts (multipliers) x U12 from every other 16-row tile.  Products are
 //      computed transposed, so that a lane's four accumulators are four columns of one row and a tile is read and
 //      written as 128-byte runs of the column-major workspace.
-// What remains is block diagonal with the 16x16 upper triangles U11 of the panels: lu_unpack solves those per
-// right-hand side and scatters the result into the caller's layout.
+// What remains is block diagonal with the 16x16 upper triangles U11 of the panels.
+//
+// Two kernels.  lu_block_kernel runs the panels over H alone (its trailing columns) and leaves, per panel, what a
+// right-hand side needs to follow: the multipliers (in place, in the panel's columns), the net row exchanges and
+// L11^-1.  lu_rhs_kernel then gives every block of 16 right-hand-side columns to a workgroup of its own, which keeps
+// the block in LDS through all panels (exchanges, U12, the rank-16 update of every other row tile on the matrix
+// cores, multipliers streamed from memory), solves the U11 blocks and writes the result in the caller's layout.  A
+// right-hand side is thus read once and written once instead of once per panel, and the workgroups of one instance
+// read the same multipliers at about the same time (L2 / Infinity Cache hits): the elimination's HBM traffic drops from
+// one pass over [H | R] per panel to one pass over H's trailing columns per panel plus two passes over R.
 #include "mpcx_internal.h"
 
 namespace mpcx {
@@ -34,7 +42,10 @@ struct LuArgs {
     int *failed;     // per instance
     long long count; // instances in this launch
     int nrp, ncp;
+    int ncw;         // columns the panels sweep (nrp: H alone; the right-hand sides follow in lu_rhs_kernel)
+    double *meta;    // per instance and panel: L11^-1 (256 doubles), then tcount, trow[32], tsrc[32] as ints (kMetaDoubles in all)
 };
+constexpr int kMetaDoubles = kNB * kNB + (2 * kMaxTouched + 16) / 2;  // 256 + 40
 
 // ---- pack: workspace <- [H padded with an identity block | right-hand side padded with zeros] ----
 struct PackArgs {
@@ -203,12 +214,19 @@ __global__ __launch_bounds__(kThreads) void lu_block_kernel(LuArgs p) {
             *tcount = n;
         }
         __syncthreads();
+        if (p.meta) {  // what the right-hand sides need to follow this panel
+            double *mt = p.meta + ((size_t)blockIdx.x * (nrp / kNB) + k0 / kNB) * kMetaDoubles;
+            if (tid < kNB * kNB) mt[tid] = linv[tid];
+            int *mi = (int *)(mt + kNB * kNB);
+            if (tid == 0) mi[0] = *tcount;
+            if (tid < kMaxTouched) { mi[1 + tid] = trow[tid]; mi[1 + kMaxTouched + tid] = tsrc[tid]; }
+        }
         // 3. the columns to the right, one block of 16 per wavefront at a time
         const int ntouched = *tcount;
         d4 la;  // A operand of the triangular solve: (L11^-1)[lane & 15][(lane >> 4) + 4 kk]
 #pragma unroll
         for (int q = 0; q < 4; ++q) la[q] = linv[(lane & 15) * kNB + (lane >> 4) + 4 * q];
-        for (int c0 = k0 + kNB + wv * kNB; c0 < ncp; c0 += kWaves * kNB) {
+        for (int c0 = k0 + kNB + wv * kNB; c0 < p.ncw; c0 += kWaves * kNB) {
             // exchanges: read every touched row's source first, then write (registers in between)
             double hold[kMaxTouched * kNB / 64];
 #pragma unroll
@@ -288,44 +306,185 @@ __global__ __launch_bounds__(kThreads) void lu_block_kernel(LuArgs p) {
     }
 }
 
-// ---- unpack: x_p = U11_p^-1 y_p per panel and right-hand side, scattered into the caller's layout ----
-struct UnpackArgs {
-    const double *ws;
+// ---- right-hand sides: one workgroup per instance and block of 16 columns, the block resident in LDS ----
+struct RhsArgs {
+    const double *ws;    // as LuArgs::ws, after lu_block_kernel: multipliers and U11 in the H part, the packed right-hand sides behind
     const int *failed;
+    const double *meta;
     double *X;
     int *info;
-    long long first, count, W;
-    int nr, nrhs, nrp, ncp, negate;
+    long long first, count, W, total;  // total = count x blocks per instance
+    int nr, nrhs, nrp, ncp, negate, ld;
 };
 
-__global__ __launch_bounds__(256) void lu_unpack_kernel(UnpackArgs p) {
-    const int panels = p.nrp / kNB;
-    const long long per = (long long)panels * p.nrhs;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.count * per) return;
-    const long long li = idx / per, rem = idx - li * per;
-    const int c = (int)(rem / panels), pn = (int)(rem - (long long)c * panels), k0 = pn * kNB;  // panels fastest: rows contiguous
+// Leading dimension of the LDS block: the four column groups of a tile access (lane >> 4) land 16 doubles apart
+// modulo 32, so that the two groups served together use disjoint banks.
+int rhs_ld(int nrp) { return (nrp % 32 == 0) ? nrp + 16 : nrp; }
+
+// THREADS: workgroup size (>= 256); MT: row tiles per wavefront (THREADS / 64 * MT * 16 >= nrp); DB: the next panel's
+// multipliers are fetched while the current panel is applied (twice the registers).
+template <int THREADS, int MT, bool DB>
+__global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
+    extern __shared__ __align__(16) double sm[];
+    constexpr int NW = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nrp = p.nrp, ld = p.ld, npan = nrp / kNB, nblk = (p.ncp - nrp) / kNB;
+    // Workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (instance, block) pairs, so
+    // that the blocks of one instance, which read the same multipliers, share one L2.
+    const long long per_xcd = (p.total + 7) / 8;
+    const long long item = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || item >= p.total) return;
+    const long long li = item / nblk;
+    const int bk = (int)(item - li * nblk), c0 = bk * kNB;
     const long long b = p.first + li;
-    const double *A = p.ws + (size_t)li * p.nrp * p.ncp;
+    const double *A = p.ws + (size_t)li * nrp * p.ncp;
+    double *blk = sm;                       // [16][ld]: blk[c * ld + row]
+    double *u12s = blk + (size_t)kNB * ld;  // [16][16]: u12s[row * 16 + col]
+    double *linv = u12s + kNB * kNB;        // [16][16]
+    int *tmeta = (int *)(linv + kNB * kNB); // tcount, trow[32], tsrc[32]
     const bool bad = p.failed[li] != 0;
-    if (p.info && rem == 0) p.info[b] = bad ? 1 : 0;
-    double x[kNB];
-#pragma unroll
-    for (int i = 0; i < kNB; ++i) x[i] = A[(size_t)(p.nrp + c) * p.nrp + k0 + i];
-#pragma unroll
-    for (int i = kNB - 1; i >= 0; --i) {
-        double s = x[i];
-#pragma unroll
-        for (int q = kNB - 1; q >= 0; --q)
-            if (q > i) s -= A[(size_t)(k0 + q) * p.nrp + k0 + i] * x[q];
-        x[i] = s / A[(size_t)(k0 + i) * p.nrp + k0 + i];
-    }
-    const double sign = p.negate ? -1.0 : 1.0;
+    if (p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
     const long long ER = (long long)p.nr * p.nrhs;
+    if (bad) {  // uniform over the workgroup
+        for (int e = tid; e < kNB * p.nr; e += THREADS) {
+            const int c = e / p.nr, row = e - c * p.nr;
+            if (c0 + c < p.nrhs) p.X[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        return;
+    }
+    const int kq = lane >> 4, l15 = lane & 15;
+    const int lofs = kq * nrp + l15;  // a lane's place in a tile of multipliers: + panel's first column, + 4 q columns, + r0
+    const double *meta = p.meta + (size_t)li * npan * kMetaDoubles;
+    double lb[DB ? 2 : 1][MT][4];
+    auto fetch_multipliers = [&](int pn, double(&dst)[MT][4]) {
 #pragma unroll
-    for (int i = 0; i < kNB; ++i)
-        if (k0 + i < p.nr)
-            p.X[elem_index(b, (long long)c * p.nr + k0 + i, ER, p.W)] = bad ? __longlong_as_double(0x7ff8000000000000LL) : sign * x[i];
+        for (int u = 0; u < MT; ++u) {
+            const int t = wv + NW * u;
+            if (t < npan && t != pn) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[u][q] = A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
+            }
+        }
+    };
+    // what a thread carries of a panel's description: one entry of L11^-1 and one int of the exchange lists
+    double m_linv = 0.0;
+    int m_int = 0;
+    auto fetch_meta = [&](int pn) {
+        const double *mt = meta + (size_t)pn * kMetaDoubles;
+        if (tid < kNB * kNB) m_linv = mt[tid];
+        if (tid < 1 + 2 * kMaxTouched) m_int = ((const int *)(mt + kNB * kNB))[tid];
+    };
+    fetch_meta(0);
+    fetch_multipliers(0, lb[0]);
+    {
+        const double *src = A + (size_t)(nrp + c0) * nrp;
+        for (int e = tid; e < kNB * nrp; e += THREADS) {
+            const int c = e / nrp, row = e - c * nrp;
+            blk[(size_t)c * ld + row] = src[e];
+        }
+    }
+    auto panel_step = [&](int pn, double(&cur)[MT][4], double(&nxt)[MT][4]) {
+        const int k0 = pn * kNB;
+        if (tid < kNB * kNB) linv[tid] = m_linv;
+        if (tid < 1 + 2 * kMaxTouched) tmeta[tid] = m_int;
+        __syncthreads();  // also orders the previous panel's updates (and the initial load) before the reads below
+        if (pn + 1 < npan) {
+            fetch_meta(pn + 1);
+            if (DB) fetch_multipliers(pn + 1, nxt);
+        }
+        // Rows after the panel's exchanges, read where they lie before them: the 16 pivot rows feed U12 = L11^-1 T,
+        // the displaced rows (entries 16.. of the list) are carried over.
+        const int ntouched = tmeta[0];
+        double uv = 0.0, moved = 0.0;
+        const int i = tid & 15, c = (tid >> 4) & 15;
+        if (tid < kNB * kNB) {
+#pragma unroll 4
+            for (int k = 0; k < kNB; ++k) uv = fma(linv[i * kNB + k], blk[c * ld + tmeta[1 + kMaxTouched + k]], uv);
+            if (kNB + i < ntouched) moved = blk[(size_t)c * ld + tmeta[1 + kMaxTouched + kNB + i]];
+        }
+        __syncthreads();
+        if (tid < kNB * kNB) {
+            blk[(size_t)c * ld + k0 + i] = uv;
+            u12s[i * kNB + c] = uv;
+            if (kNB + i < ntouched) blk[(size_t)c * ld + tmeta[1 + kNB + i]] = moved;
+        }
+        __syncthreads();
+        d4 nu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nu[q] = -u12s[(kq + 4 * q) * kNB + l15];
+        const int cofs = kq * ld + l15;  // + 4 q columns, + r0
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const int t = wv + NW * u;
+            if (t < npan && t != pn) {
+                const int r0 = t * kNB;
+                d4 acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = blk[cofs + 4 * q * ld + r0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], cur[u][q], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) blk[cofs + 4 * q * ld + r0] = acc[q];
+            }
+        }
+        if (!DB && pn + 1 < npan) fetch_multipliers(pn + 1, cur);
+    };
+    if (DB) {
+        int pn = 0;
+        for (; pn + 1 < npan; pn += 2) {
+            panel_step(pn, lb[0], lb[DB ? 1 : 0]);
+            panel_step(pn + 1, lb[DB ? 1 : 0], lb[0]);
+        }
+        if (pn < npan) panel_step(pn, lb[0], lb[DB ? 1 : 0]);
+    } else {
+        for (int pn = 0; pn < npan; ++pn) panel_step(pn, lb[0], lb[0]);
+    }
+    __syncthreads();
+    // x_p = U11_p^-1 y_p per panel and column, in place (a thread owns its 16 entries of the block)
+    for (int e = tid; e < npan * kNB; e += THREADS) {
+        const int c = e / npan, pn = e - c * npan, k0 = pn * kNB;
+        double *x = blk + (size_t)c * ld + k0;
+        const double *U = A + (size_t)k0 * nrp + k0;  // U[q * nrp + i] = U11[i][q]
+#pragma unroll 1
+        for (int i = kNB - 1; i >= 0; --i) {
+            double s = x[i];
+#pragma unroll 1
+            for (int q = kNB - 1; q > i; --q) s -= U[(size_t)q * nrp + i] * x[q];
+            x[i] = s / U[(size_t)i * nrp + i];
+        }
+    }
+    __syncthreads();
+    const double sign = p.negate ? -1.0 : 1.0;
+    for (int e = tid; e < kNB * p.nr; e += THREADS) {
+        const int c = e / p.nr, row = e - c * p.nr;
+        if (c0 + c < p.nrhs) p.X[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] = sign * blk[(size_t)c * ld + row];
+    }
+}
+
+template <int THREADS, int MT, bool DB>
+int launch_rhs(const RhsArgs &ra, size_t lds, hipStream_t s) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)lu_rhs_kernel<THREADS, MT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long long per_xcd = (ra.total + 7) / 8;
+    hipLaunchKernelGGL((lu_rhs_kernel<THREADS, MT, DB>), dim3((unsigned)(per_xcd * 8)), dim3(THREADS), lds, s, ra);
+    return 0;
+}
+
+constexpr int kRhsMaxRows = 8 * 10 * kNB;  // the widest variant: 8 wavefronts x 10 tiles
+
+int launch_rhs_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
+    const int npan = ra.nrp / kNB;
+    if (npan <= 8) return launch_rhs<256, 2, true>(ra, lds, s);
+    if (npan <= 16) return launch_rhs<256, 4, true>(ra, lds, s);
+    if (npan <= 32) return launch_rhs<512, 4, true>(ra, lds, s);
+    if (npan <= 56) return launch_rhs<512, 7, true>(ra, lds, s);
+    return launch_rhs<512, 10, false>(ra, lds, s);
+}
+
+size_t rhs_lds_bytes(int nrp) {
+    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB) * sizeof(double) + sizeof(int) * (2 * kMaxTouched + 4);
 }
 
 size_t lu_lds_bytes(int nrp) {
@@ -338,18 +497,21 @@ size_t lu_lds_bytes(int nrp) {
 // Doubles of workspace one instance needs, and the ints for the failure flags ride behind them.
 size_t solve_large_ws_doubles(int nr, int nrhs) {
     const size_t nrp = (size_t)((nr + 15) & ~15), ncp = nrp + (size_t)((nrhs + 15) & ~15);
-    return nrp * ncp + 1;  // + one slot for the instance's failure flag
+    return nrp * ncp + 1 + (nrp / kNB) * kMetaDoubles;  // + the instance's failure flag + what each panel leaves for the right-hand sides
 }
 
-bool solve_large_supports(int nr) { return lu_lds_bytes((nr + 15) & ~15) <= 160 * 1024; }
+bool solve_large_supports(int nr) {
+    const int nrp = (nr + 15) & ~15;
+    return lu_lds_bytes(nrp) <= 160 * 1024 && rhs_lds_bytes(nrp) <= 160 * 1024 && nrp <= kRhsMaxRows;
+}
 
 // R / Q as in the small kernels (Q != nullptr: R is Gamma and the right-hand side Gamma^T blockdiag(Q)).  `ws` holds
 // `ws_doubles` doubles; the batch is processed in as many launches as that takes.
 int launch_solve_large(const double *H, const double *R, const double *Q, int r, double *X, int *info, long long batch,
                        long long W, int nr, int nrhs, int negate, double *ws, size_t ws_doubles, hipStream_t s) {
     const int nrp = (nr + 15) & ~15, ncp = nrp + ((nrhs + 15) & ~15);
-    const size_t lds_bytes = lu_lds_bytes(nrp);
-    if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
+    const size_t lds_bytes = lu_lds_bytes(nrp), rhs_bytes = rhs_lds_bytes(nrp);
+    if (!solve_large_supports(nr)) return MPCX_ERR_UNSUPPORTED;
     const size_t per = solve_large_ws_doubles(nr, nrhs);
     const long long chunk = (long long)(ws_doubles / per);
     if (chunk < 1) return MPCX_ERR_UNSUPPORTED;
@@ -360,6 +522,7 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
     for (long long first = 0; first < batch; first += chunk) {
         const long long count = (batch - first < chunk) ? batch - first : chunk;
         int *failed = (int *)(ws + (size_t)count * nrp * ncp);  // behind the matrices of this launch
+        double *meta = ws + (size_t)count * nrp * ncp + (size_t)count;
         hipError_t e = hipMemsetAsync(failed, 0, (size_t)count * sizeof(int), s);
         if (e != hipSuccess) return (int)e;
         const long long elems = count * (long long)nrp * ncp;
@@ -378,11 +541,15 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         } else {
             hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa, ncp);
         }
-        LuArgs la{ws, failed, count, nrp, ncp};
+        LuArgs la{ws, failed, count, nrp, ncp, nrp, meta};
         hipLaunchKernelGGL(lu_block_kernel, dim3((unsigned)count), dim3(kThreads), lds_bytes, s, la);
-        const long long uthreads = count * (long long)(nrp / kNB) * nrhs;
-        UnpackArgs ua{ws, failed, X, info, first, count, W, nr, nrhs, nrp, ncp, negate};
-        hipLaunchKernelGGL(lu_unpack_kernel, dim3((unsigned)((uthreads + 255) / 256)), dim3(256), 0, s, ua);
+        const long long total = count * (long long)((ncp - nrp) / kNB), per_xcd = (total + 7) / 8;
+        if (per_xcd * 8 > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+        RhsArgs ra{ws, failed, meta, X, info, first, count, W, total, nr, nrhs, nrp, ncp, negate, rhs_ld(nrp)};
+        if (total > 0) {
+            const int rc = launch_rhs_any(ra, rhs_bytes, s);
+            if (rc != 0) return rc;
+        }
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
