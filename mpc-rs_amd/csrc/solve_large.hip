@@ -1,6 +1,6 @@
 // Solve with the condensed Hessian for systems too large for LDS (v m from 65 up to about 1200 unknowns): blocked
-// elimination with partial pivoting on the augmented matrix [H | R] held in a device workspace, one workgroup per
-// instance, trailing updates on the FP64 matrix cores.
+// elimination with partial pivoting, H held in a device workspace (one workgroup per instance) and the right-hand
+// sides in LDS (one workgroup per instance and 16 columns), updates on the FP64 matrix cores.
 //
 // Reference: src/control/controller.rs:93-96 (try_inverse of the Hessian, then H^-1 M^T W4).  Pivot rule and failure
 // test are those of an LU with partial pivoting, as nalgebra's: at column k the largest |a[i][k]| among the rows not
@@ -11,7 +11,8 @@
 //      in rows >= k0 + j, exchanged into row k0 + j, and every other row outside the panel's pivot block, the rows
 //      above k0 included, gets its multiplier l = a / pivot and is reduced in the remaining panel columns.
 //      Eliminating above as well as below (block Gauss-Jordan) means there is no backward sweep over the matrix.
-//   2. each wavefront takes blocks of 16 columns to the right (the rest of H and the right-hand sides): it applies the
+//   2. each wavefront takes blocks of 16 columns to the right (the rest of H; a block of right-hand sides is treated
+//      the same way by its own workgroup): it applies the
 //      panel's row exchanges, forms U12 = L11^-1 T for the 16 pivot rows (one 16x16x16 product with the inverse of the
 //      panel's unit lower triangle) and subtracts (multipliers) x U12 from every other 16-row tile.  Products are
 //      computed transposed, so that a lane's four accumulators are four columns of one row and a tile is read and
@@ -22,10 +23,11 @@
 // right-hand side needs to follow: the multipliers (in place, in the panel's columns), the net row exchanges and
 // L11^-1.  lu_rhs_kernel then gives every block of 16 right-hand-side columns to a workgroup of its own, which keeps
 // the block in LDS through all panels (exchanges, U12, the rank-16 update of every other row tile on the matrix
-// cores, multipliers streamed from memory), solves the U11 blocks and writes the result in the caller's layout.  A
-// right-hand side is thus read once and written once instead of once per panel, and the workgroups of one instance
-// read the same multipliers at about the same time (L2 / Infinity Cache hits): the elimination's HBM traffic drops from
-// one pass over [H | R] per panel to one pass over H's trailing columns per panel plus two passes over R.
+// cores, multipliers streamed from memory), solves the U11 blocks and writes the result in the caller's layout.  The
+// block is formed from the caller's arrays as it is loaded (Gamma^T blockdiag(Q) included), so a right-hand side is
+// read once and its solution written once, and never enters the workspace; the workgroups of one instance read the
+// same multipliers at about the same time (L2 / Infinity Cache hits).  HBM traffic of the elimination: one pass over
+// H's trailing columns per panel, plus one pass over the right-hand sides and one over the result.
 #include "mpcx_internal.h"
 
 namespace mpcx {
@@ -33,96 +35,59 @@ namespace {
 
 using d4 = __attribute__((ext_vector_type(4))) double;
 constexpr int kNB = 16;
-constexpr int kThreads = 512;
-constexpr int kWaves = kThreads / 64;
 constexpr int kMaxTouched = 2 * kNB;
 
 struct LuArgs {
-    double *ws;      // per instance: column-major nrp x ncp, leading dimension nrp
+    double *ws;      // per instance: H padded to nrp x nrp, column-major
     int *failed;     // per instance
     long long count; // instances in this launch
-    int nrp, ncp;
-    int ncw;         // columns the panels sweep (nrp: H alone; the right-hand sides follow in lu_rhs_kernel)
-    double *meta;    // per instance and panel: L11^-1 (256 doubles), then tcount, trow[32], tsrc[32] as ints (kMetaDoubles in all)
+    int nrp;
+    double *meta;    // per instance and panel: L11^-1 and U11^-1 (256 doubles each), then tcount, trow[32], tsrc[32] as ints (kMetaDoubles in all)
 };
-constexpr int kMetaDoubles = kNB * kNB + (2 * kMaxTouched + 16) / 2;  // 256 + 40
+constexpr int kMetaInts = 2 * kNB * kNB;                               // where the ints start, in doubles
+constexpr int kMetaDoubles = kMetaInts + (2 * kMaxTouched + 16) / 2;  // 512 + 40
 
-// ---- pack: workspace <- [H padded with an identity block | right-hand side padded with zeros] ----
+// ---- pack: workspace <- H padded with an identity block ----
 struct PackArgs {
-    const double *H, *R, *Q;  // Q != nullptr: R is Gamma (fr x nr per instance) and the right-hand side is Gamma^T blockdiag(Q)
+    const double *H;
     double *ws;
     long long first, count, W;  // instances [first, first + count) of the batch
-    int nr, nrhs, r, nrp, ncp;
+    int nr, nrp;
 };
 
-// Elementwise part: the H block (with its identity padding) and, when the right-hand side is given as such (Q == nullptr),
-// the right-hand side columns.  `ncols` = nrp or ncp accordingly.  Lanes run along the rows of a column on both sides.
-__global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p, int ncols) {
-    const long long per = (long long)p.nrp * ncols;
+// Lanes run along the rows of a column on both sides.
+__global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p) {
+    const long long per = (long long)p.nrp * p.nrp;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.count * per) return;
     const long long li = idx / per, e = idx - li * per;
     const int col = (int)(e / p.nrp), row = (int)(e - (long long)col * p.nrp);
     const long long b = p.first + li;
-    double v;
-    if (col < p.nrp) {
-        v = (row < p.nr && col < p.nr) ? p.H[elem_index(b, (long long)col * p.nr + row, (long long)p.nr * p.nr, p.W)]
-                                       : (row == col ? 1.0 : 0.0);
-    } else {
-        const int c = col - p.nrp;
-        v = (row < p.nr && c < p.nrhs) ? p.R[elem_index(b, (long long)c * p.nr + row, (long long)p.nr * p.nrhs, p.W)] : 0.0;
-    }
-    p.ws[li * (long long)p.nrp * p.ncp + e] = v;
-}
-
-// Right-hand side Gamma^T blockdiag(Q) (controller.rs:96, M^T W4): column c = blk r + a2, row k is
-// sum_a Gamma[blk r + a][k] Q[a][a2].  Gamma is (f r) x (v m) column-major, so its rows are the contiguous direction
-// while the workspace wants k contiguous: a workgroup moves a tile of 16 unknowns x TC rows of Gamma (TC a multiple of r)
-// through LDS, reading along Gamma's rows and writing along the workspace's.
-constexpr int kTileK = 16, kTileCMax = 64;
-__global__ __launch_bounds__(256) void lu_pack_gamma_kernel(PackArgs p, int TC, int CT, int KT) {
-    __shared__ double tile[kTileK][kTileCMax + 1];
-    long long t = blockIdx.x;
-    const int kt = (int)(t % KT);
-    t /= KT;
-    const int ct = (int)(t % CT);
-    const long long li = t / CT, b = p.first + li;
-    const int k0 = kt * kTileK, c0 = ct * TC, r = p.r;
-    const long long ER = (long long)p.nr * p.nrhs;
-    for (int e = threadIdx.x; e < kTileK * TC; e += 256) {
-        const int kk = e / TC, cc = e - kk * TC, k = k0 + kk, cp = c0 + cc;
-        tile[kk][cc] = (k < p.nr && cp < p.nrhs) ? p.R[elem_index(b, (long long)k * p.nrhs + cp, ER, p.W)] : 0.0;
-    }
-    __syncthreads();
-    double *out = p.ws + li * (long long)p.nrp * p.ncp + (long long)p.nrp * p.nrp;
-    const int ncr = p.ncp - p.nrp;  // padded right-hand side columns
-    for (int e = threadIdx.x; e < kTileK * TC; e += 256) {
-        const int cc = e / kTileK, kk = e - cc * kTileK, c = c0 + cc, k = k0 + kk;
-        if (c >= ncr) continue;
-        double v = 0.0;
-        if (k < p.nr && c < p.nrhs) {
-            const int blk = cc / r, a2 = cc - blk * r;
-            for (int a = 0; a < r; ++a) v += tile[kk][blk * r + a] * p.Q[a2 * r + a];
-        }
-        out[(long long)c * p.nrp + k] = v;
-    }
+    p.ws[idx] = (row < p.nr && col < p.nr) ? p.H[elem_index(b, (long long)col * p.nr + row, (long long)p.nr * p.nr, p.W)]
+                                           : (row == col ? 1.0 : 0.0);
 }
 
 // ---- factor / eliminate: one workgroup per instance ----
-__global__ __launch_bounds__(kThreads) void lu_block_kernel(LuArgs p) {
+// THREADS = 512 with the pipelined column sweep for large systems (HBM bound); 256 and a plain sweep for small ones,
+// whose time goes into the barriers of the panel factorization: fewer registers and a smaller workgroup let several
+// instances share a CU.
+template <int THREADS, bool PIPE>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_block_kernel(LuArgs p) {
+    constexpr int kThreads = THREADS, kWaves = THREADS / 64;
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nrp = p.nrp, ncp = p.ncp;
+    const int nrp = p.nrp;
     double *panel = sm;                                  // [16][nrp]: panel[j * nrp + row]
     double *linv = panel + (size_t)kNB * nrp;            // [16][16]: linv[i * 16 + k] = (L11^-1)[i][k]
-    double *tiles = linv + kNB * kNB;                    // per wavefront [16][16]: T[row * 16 + col]
+    double *uinv = linv + kNB * kNB;                     // [16][16]: uinv[i * 16 + k] = (U11^-1)[i][k]
+    double *tiles = uinv + kNB * kNB;                    // per wavefront [16][16]: T[row * 16 + col]
     double *red_val = tiles + kWaves * kNB * kNB;        // [kWaves]
     int *red_idx = (int *)(red_val + kWaves);            // [kWaves]
     int *ipiv = red_idx + kWaves;                        // [16]
     int *trow = ipiv + kNB;                              // [32] rows whose content changes with the panel's exchanges
     int *tsrc = trow + kMaxTouched;                      // [32] the row whose old content each of them receives
     int *tcount = tsrc + kMaxTouched;                    // [1]
-    double *A = p.ws + (size_t)blockIdx.x * nrp * ncp;
+    double *A = p.ws + (size_t)blockIdx.x * nrp * nrp;
     double *mytile = tiles + wv * kNB * kNB;
 
     for (int k0 = 0; k0 < nrp; k0 += kNB) {
@@ -197,6 +162,16 @@ __global__ __launch_bounds__(kThreads) void lu_block_kernel(LuArgs p) {
                 linv[i * kNB + tid] = s;
             }
         }
+        if (tid >= 128 && tid < 128 + kNB) {  // column j of U11^-1 by backward substitution on a unit vector (a third wavefront)
+            const int j = tid - 128;  // the column is kept in LDS as it grows: a lane reads back only what it wrote
+#pragma unroll 1
+            for (int i = kNB - 1; i >= 0; --i) {
+                double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll 5
+                for (int q = kNB - 1; q > i; --q) s -= panel[(size_t)q * nrp + k0 + i] * uinv[q * kNB + j];
+                uinv[i * kNB + j] = s / panel[(size_t)i * nrp + k0 + i];
+            }
+        }
         if (tid == 64) {  // another wavefront than the one inverting L11
             int n = kNB;
             for (int q = 0; q < kNB; ++q) { trow[q] = k0 + q; tsrc[q] = k0 + q; }
@@ -216,8 +191,8 @@ __global__ __launch_bounds__(kThreads) void lu_block_kernel(LuArgs p) {
         __syncthreads();
         if (p.meta) {  // what the right-hand sides need to follow this panel
             double *mt = p.meta + ((size_t)blockIdx.x * (nrp / kNB) + k0 / kNB) * kMetaDoubles;
-            if (tid < kNB * kNB) mt[tid] = linv[tid];
-            int *mi = (int *)(mt + kNB * kNB);
+            if (tid < kNB * kNB) { mt[tid] = linv[tid]; mt[kNB * kNB + tid] = uinv[tid]; }
+            int *mi = (int *)(mt + kMetaInts);
             if (tid == 0) mi[0] = *tcount;
             if (tid < kMaxTouched) { mi[1 + tid] = trow[tid]; mi[1 + kMaxTouched + tid] = tsrc[tid]; }
         }
@@ -226,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void lu_block_kernel(LuArgs p) {
         d4 la;  // A operand of the triangular solve: (L11^-1)[lane & 15][(lane >> 4) + 4 kk]
 #pragma unroll
         for (int q = 0; q < 4; ++q) la[q] = linv[(lane & 15) * kNB + (lane >> 4) + 4 * q];
-        for (int c0 = k0 + kNB + wv * kNB; c0 < p.ncw; c0 += kWaves * kNB) {
+        for (int c0 = k0 + kNB + wv * kNB; c0 < nrp; c0 += kWaves * kNB) {
             // exchanges: read every touched row's source first, then write (registers in between)
             double hold[kMaxTouched * kNB / 64];
 #pragma unroll
@@ -260,6 +235,22 @@ __global__ __launch_bounds__(kThreads) void lu_block_kernel(LuArgs p) {
             double *cbase = A + (size_t)(c0 + (lane >> 4)) * nrp + (lane & 15);  // + r0, + 4 q columns
             auto row0 = [&](int t) { return (t < pidx ? t : t + 1) * kNB; };
             d4 buf[4], nbuf[4];
+            if (!PIPE) {
+                for (int t = 0; t < nt; ++t) {
+                    const int r0 = row0(t);
+                    d4 acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = cbase[(size_t)(4 * q) * nrp + r0];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double lb = panel[(size_t)((lane >> 4) + 4 * q) * nrp + r0 + (lane & 15)];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cbase[(size_t)(4 * q) * nrp + r0] = acc[q];
+                }
+                continue;
+            }
             if (nt4 > 0) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -308,14 +299,20 @@ __global__ __launch_bounds__(kThreads) void lu_block_kernel(LuArgs p) {
 
 // ---- right-hand sides: one workgroup per instance and block of 16 columns, the block resident in LDS ----
 struct RhsArgs {
-    const double *ws;    // as LuArgs::ws, after lu_block_kernel: multipliers and U11 in the H part, the packed right-hand sides behind
+    const double *ws;    // as LuArgs::ws, after lu_block_kernel: multipliers, and U11 in the diagonal blocks
     const int *failed;
     const double *meta;
+    const double *R, *Q; // Q != nullptr: R is Gamma (fr x nr per instance) and the right-hand side is Gamma^T blockdiag(Q)
     double *X;
     int *info;
     long long first, count, W, total;  // total = count x blocks per instance
-    int nr, nrhs, nrp, ncp, negate, ld;
+    int nr, nrhs, r, nrp, negate, ld, kc;  // kc: unknowns per staging round of the Gamma^T blockdiag(Q) product
 };
+#ifndef MPCX_RHS_ABLATE
+#define MPCX_RHS_ABLATE 0  // experiments only (wrong results): 1 no block load, 2 no panels, 4 no tile updates, 8 no U11 step, 16 no write
+#endif
+constexpr int kStageDoubles = 1024;  // LDS staging: Gamma's rows while the block is formed, four U11 blocks at a time at the end
+constexpr int kMaxWeightBlock = 64;  // widest output weight block r served
 
 // Leading dimension of the LDS block: the four column groups of a tile access (lane >> 4) land 16 doubles apart
 // modulo 32, so that the two groups served together use disjoint banks.
@@ -328,7 +325,7 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
     extern __shared__ __align__(16) double sm[];
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nrp = p.nrp, ld = p.ld, npan = nrp / kNB, nblk = (p.ncp - nrp) / kNB;
+    const int nrp = p.nrp, ld = p.ld, npan = nrp / kNB, nblk = (p.nrhs + kNB - 1) / kNB;
     // Workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (instance, block) pairs, so
     // that the blocks of one instance, which read the same multipliers, share one L2.
     const long long per_xcd = (p.total + 7) / 8;
@@ -337,11 +334,12 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
     const long long li = item / nblk;
     const int bk = (int)(item - li * nblk), c0 = bk * kNB;
     const long long b = p.first + li;
-    const double *A = p.ws + (size_t)li * nrp * p.ncp;
+    const double *A = p.ws + (size_t)li * nrp * nrp;
     double *blk = sm;                       // [16][ld]: blk[c * ld + row]
     double *u12s = blk + (size_t)kNB * ld;  // [16][16]: u12s[row * 16 + col]
     double *linv = u12s + kNB * kNB;        // [16][16]
     int *tmeta = (int *)(linv + kNB * kNB); // tcount, trow[32], tsrc[32]
+    double *stage = linv + kNB * kNB + (2 * kMaxTouched + 4) / 2;  // kStageDoubles: Gamma's rows at the start, U11 blocks at the end
     const bool bad = p.failed[li] != 0;
     if (p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
     const long long ER = (long long)p.nr * p.nrhs;
@@ -362,7 +360,8 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
             const int t = wv + NW * u;
             if (t < npan && t != pn) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dst[u][q] = A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
+                for (int q = 0; q < 4; ++q)
+                    dst[u][q] = A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
             }
         }
     };
@@ -372,18 +371,63 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
     auto fetch_meta = [&](int pn) {
         const double *mt = meta + (size_t)pn * kMetaDoubles;
         if (tid < kNB * kNB) m_linv = mt[tid];
-        if (tid < 1 + 2 * kMaxTouched) m_int = ((const int *)(mt + kNB * kNB))[tid];
+        if (tid < 1 + 2 * kMaxTouched) m_int = ((const int *)(mt + kMetaInts))[tid];
     };
     fetch_meta(0);
     fetch_multipliers(0, lb[0]);
-    {
-        const double *src = A + (size_t)(nrp + c0) * nrp;
+    // The block: 16 columns of the right-hand side, rows beyond nr and columns beyond nrhs zero.
+    if (MPCX_RHS_ABLATE & 1) {
+    } else if (p.Q == nullptr) {
         for (int e = tid; e < kNB * nrp; e += THREADS) {
             const int c = e / nrp, row = e - c * nrp;
-            blk[(size_t)c * ld + row] = src[e];
+            blk[c * ld + row] = (row < p.nr && c0 + c < p.nrhs) ? p.R[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] : 0.0;
         }
+    } else {
+        // Gamma^T blockdiag(Q) (controller.rs:96, M^T W4): column c = g r + a2, row k is sum_a Gamma[g r + a][k] Q[a2][a]
+        // (Q stored column-major: Q[a2 * r + a]).  Gamma is (f r) x (v m) column-major, so the rows [lo, hi) of Gamma
+        // that the block's columns touch are one contiguous run per unknown k: kc unknowns at a time go through LDS.
+        const int r = p.r, lo = (c0 / r) * r;
+        int hi = ((c0 + kNB - 1) / r + 1) * r;
+        if (hi > p.nrhs) hi = p.nrhs;
+        const int w = hi - lo, kc = p.kc;
+        const bool q_lds = r * r <= kNB * kNB;  // the weight block rides in LDS (the U12 buffer is idle until the panels start)
+        if (q_lds)
+            for (int e = tid; e < r * r; e += THREADS) u12s[e] = p.Q[e];
+        const double *qw = q_lds ? u12s : p.Q;
+        constexpr int PER = (kStageDoubles + THREADS - 1) / THREADS;
+        double greg[PER];
+        auto fetch_gamma = [&](int kb) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int e = tid + u * THREADS, kk = e / w, j = e - kk * w, k = kb + kk;
+                greg[u] = (e < kc * w && k < p.nr) ? p.R[elem_index(b, (long long)k * p.nrhs + lo + j, ER, p.W)] : 0.0;
+            }
+        };
+        fetch_gamma(0);
+        for (int kb = 0; kb < nrp; kb += kc) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if (tid + u * THREADS < kc * w) stage[tid + u * THREADS] = greg[u];
+            __syncthreads();
+            if (kb + kc < nrp) fetch_gamma(kb + kc);
+            for (int e = tid; e < kc * kNB; e += THREADS) {
+                const int c = e / kc, kk = e - c * kc, k = kb + kk;
+                if (k >= nrp) continue;
+                double v = 0.0;
+                if (k < p.nr && c0 + c < p.nrhs) {
+                    const int g = (c0 + c) / r, a2 = (c0 + c) - g * r;
+                    const double *row = stage + kk * w + (g * r - lo), *qrow = qw + a2 * r;
+#pragma unroll 4
+                    for (int a = 0; a < r; ++a) v += row[a] * qrow[a];
+                }
+                blk[c * ld + k] = v;
+            }
+        }
+        __syncthreads();  // the weight block leaves the U12 buffer
     }
     auto panel_step = [&](int pn, double(&cur)[MT][4], double(&nxt)[MT][4]) {
+        if ((MPCX_RHS_ABLATE & 2) && pn >= 0) return;
         const int k0 = pn * kNB;
         if (tid < kNB * kNB) linv[tid] = m_linv;
         if (tid < 1 + 2 * kMaxTouched) tmeta[tid] = m_int;
@@ -416,7 +460,7 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             const int t = wv + NW * u;
-            if (t < npan && t != pn) {
+            if (t < npan && t != pn && !(MPCX_RHS_ABLATE & 4)) {
                 const int r0 = t * kNB;
                 d4 acc;
 #pragma unroll
@@ -440,22 +484,24 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
         for (int pn = 0; pn < npan; ++pn) panel_step(pn, lb[0], lb[0]);
     }
     __syncthreads();
-    // x_p = U11_p^-1 y_p per panel and column, in place (a thread owns its 16 entries of the block)
-    for (int e = tid; e < npan * kNB; e += THREADS) {
-        const int c = e / npan, pn = e - c * npan, k0 = pn * kNB;
-        double *x = blk + (size_t)c * ld + k0;
-        const double *U = A + (size_t)k0 * nrp + k0;  // U[q * nrp + i] = U11[i][q]
-#pragma unroll 1
-        for (int i = kNB - 1; i >= 0; --i) {
-            double s = x[i];
-#pragma unroll 1
-            for (int q = kNB - 1; q > i; --q) s -= U[(size_t)q * nrp + i] * x[q];
-            x[i] = s / U[(size_t)i * nrp + i];
+    // x_p = U11_p^-1 y_p per panel, in place: one 16x16x16 product per panel, panels dealt to the wavefronts
+    for (int pn = wv; pn < npan && !(MPCX_RHS_ABLATE & 8); pn += NW) {
+        const double *ui = meta + (size_t)pn * kMetaDoubles + kNB * kNB;
+        d4 x = {0.0, 0.0, 0.0, 0.0};
+        double ua[4], yb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ua[q] = ui[l15 * kNB + kq + 4 * q];              // A operand: U11^-1[i = lane & 15][k]
+            yb[q] = blk[l15 * ld + pn * kNB + kq + 4 * q];   // B operand: y[k][column lane & 15]
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[q], yb[q], x, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) blk[l15 * ld + pn * kNB + kq + 4 * q] = x[q];  // D[i = (lane >> 4) + 4 q][column lane & 15]
     }
     __syncthreads();
     const double sign = p.negate ? -1.0 : 1.0;
-    for (int e = tid; e < kNB * p.nr; e += THREADS) {
+    for (int e = tid; e < kNB * p.nr && !(MPCX_RHS_ABLATE & 16); e += THREADS) {
         const int c = e / p.nr, row = e - c * p.nr;
         if (c0 + c < p.nrhs) p.X[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] = sign * blk[(size_t)c * ld + row];
     }
@@ -484,20 +530,25 @@ int launch_rhs_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
 }
 
 size_t rhs_lds_bytes(int nrp) {
-    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB) * sizeof(double) + sizeof(int) * (2 * kMaxTouched + 4);
+    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2 + kStageDoubles) * sizeof(double);
 }
 
+constexpr int kSmallRows = 256;  // up to here the 256-thread panel kernel
+int lu_threads(int nrp) { return nrp <= kSmallRows ? 256 : 512; }
+
 size_t lu_lds_bytes(int nrp) {
-    size_t d = (size_t)kNB * nrp + kNB * kNB + kWaves * kNB * kNB + kWaves;
-    return d * sizeof(double) + sizeof(int) * (kWaves + kNB + 2 * kMaxTouched + 4);
+    const int waves = lu_threads(nrp) / 64;
+    size_t d = (size_t)kNB * nrp + 2 * kNB * kNB + waves * kNB * kNB + waves;
+    return d * sizeof(double) + sizeof(int) * (waves + kNB + 2 * kMaxTouched + 4);
 }
 
 }  // namespace
 
 // Doubles of workspace one instance needs, and the ints for the failure flags ride behind them.
 size_t solve_large_ws_doubles(int nr, int nrhs) {
-    const size_t nrp = (size_t)((nr + 15) & ~15), ncp = nrp + (size_t)((nrhs + 15) & ~15);
-    return nrp * ncp + 1 + (nrp / kNB) * kMetaDoubles;  // + the instance's failure flag + what each panel leaves for the right-hand sides
+    const size_t nrp = (size_t)((nr + 15) & ~15);
+    (void)nrhs;  // right-hand sides never enter the workspace
+    return nrp * nrp + 1 + (nrp / kNB) * kMetaDoubles;  // + the instance's failure flag + what each panel leaves for the right-hand sides
 }
 
 bool solve_large_supports(int nr) {
@@ -509,43 +560,39 @@ bool solve_large_supports(int nr) {
 // `ws_doubles` doubles; the batch is processed in as many launches as that takes.
 int launch_solve_large(const double *H, const double *R, const double *Q, int r, double *X, int *info, long long batch,
                        long long W, int nr, int nrhs, int negate, double *ws, size_t ws_doubles, hipStream_t s) {
-    const int nrp = (nr + 15) & ~15, ncp = nrp + ((nrhs + 15) & ~15);
+    const int nrp = (nr + 15) & ~15;
     const size_t lds_bytes = lu_lds_bytes(nrp), rhs_bytes = rhs_lds_bytes(nrp);
     if (!solve_large_supports(nr)) return MPCX_ERR_UNSUPPORTED;
+    if (Q != nullptr && (r < 1 || r > kMaxWeightBlock)) return MPCX_ERR_UNSUPPORTED;  // weight blocks wider than 64 outputs are not served
     const size_t per = solve_large_ws_doubles(nr, nrhs);
     const long long chunk = (long long)(ws_doubles / per);
     if (chunk < 1) return MPCX_ERR_UNSUPPORTED;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)lu_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (lds_bytes > 64 * 1024) {  // only the 512-thread variant gets there
+        hipError_t e = hipFuncSetAttribute((const void *)lu_block_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
+    }
+    int kc = 0;
+    if (Q != nullptr) {  // rows of Gamma a block of 16 columns can touch: 16 + 2 (r - 1) at most
+        const int wmax = (2 * r + 14 < nrhs) ? 2 * r + 14 : nrhs;
+        kc = kStageDoubles / (wmax > 0 ? wmax : 1);
+        if (kc > nrp) kc = nrp;
     }
     for (long long first = 0; first < batch; first += chunk) {
         const long long count = (batch - first < chunk) ? batch - first : chunk;
-        int *failed = (int *)(ws + (size_t)count * nrp * ncp);  // behind the matrices of this launch
-        double *meta = ws + (size_t)count * nrp * ncp + (size_t)count;
+        int *failed = (int *)(ws + (size_t)count * nrp * nrp);  // behind the matrices of this launch
+        double *meta = ws + (size_t)count * nrp * nrp + (size_t)count;
         hipError_t e = hipMemsetAsync(failed, 0, (size_t)count * sizeof(int), s);
         if (e != hipSuccess) return (int)e;
-        const long long elems = count * (long long)nrp * ncp;
-        const long long pblocks = (elems + 255) / 256;
+        const long long pblocks = (count * (long long)nrp * nrp + 255) / 256;
         if (pblocks > 0x7fffffffLL || count > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-        PackArgs pa{H, R, Q, ws, first, count, W, nr, nrhs, r, nrp, ncp};
-        if (Q != nullptr && r <= kTileCMax) {
-            const long long hblocks = (count * (long long)nrp * nrp + 255) / 256;
-            hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)hblocks), dim3(256), 0, s, pa, nrp);
-            const int TC = r * (kTileCMax / r), CT = (ncp - nrp + TC - 1) / TC, KT = nrp / kTileK;
-            const long long tiles = count * (long long)CT * KT;
-            if (tiles > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL(lu_pack_gamma_kernel, dim3((unsigned)tiles), dim3(256), 0, s, pa, TC, CT, KT);
-        } else if (Q != nullptr) {
-            return MPCX_ERR_UNSUPPORTED;  // weight blocks wider than 64 outputs are not served by the blocked solver
-        } else {
-            hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa, ncp);
-        }
-        LuArgs la{ws, failed, count, nrp, ncp, nrp, meta};
-        hipLaunchKernelGGL(lu_block_kernel, dim3((unsigned)count), dim3(kThreads), lds_bytes, s, la);
-        const long long total = count * (long long)((ncp - nrp) / kNB), per_xcd = (total + 7) / 8;
+        PackArgs pa{H, ws, first, count, W, nr, nrp};
+        hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa);
+        LuArgs la{ws, failed, count, nrp, meta};
+        if (lu_threads(nrp) == 256) hipLaunchKernelGGL((lu_block_kernel<256, false>), dim3((unsigned)count), dim3(256), lds_bytes, s, la);
+        else hipLaunchKernelGGL((lu_block_kernel<512, true>), dim3((unsigned)count), dim3(512), lds_bytes, s, la);
+        const long long total = count * (long long)((nrhs + kNB - 1) / kNB), per_xcd = (total + 7) / 8;
         if (per_xcd * 8 > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-        RhsArgs ra{ws, failed, meta, X, info, first, count, W, total, nr, nrhs, nrp, ncp, negate, rhs_ld(nrp)};
+        RhsArgs ra{ws, failed, meta, R, Q, X, info, first, count, W, total, nr, nrhs, r, nrp, negate, rhs_ld(nrp), kc};
         if (total > 0) {
             const int rc = launch_rhs_any(ra, rhs_bytes, s);
             if (rc != 0) return rc;
