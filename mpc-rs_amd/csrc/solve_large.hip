@@ -306,12 +306,11 @@ struct RhsArgs {
     double *X;
     int *info;
     long long first, count, W, total;  // total = count x blocks per instance
-    int nr, nrhs, r, nrp, negate, ld, kc;  // kc: unknowns per staging round of the Gamma^T blockdiag(Q) product
+    int nr, nrhs, r, nrp, negate, ld;
 };
 #ifndef MPCX_RHS_ABLATE
 #define MPCX_RHS_ABLATE 0  // experiments only (wrong results): 1 no block load, 2 no panels, 4 no tile updates, 8 no U11 step, 16 no write
 #endif
-constexpr int kStageDoubles = 1024;  // LDS staging: Gamma's rows while the block is formed, four U11 blocks at a time at the end
 constexpr int kMaxWeightBlock = 64;  // widest output weight block r served
 
 // Leading dimension of the LDS block: the four column groups of a tile access (lane >> 4) land 16 doubles apart
@@ -321,7 +320,7 @@ int rhs_ld(int nrp) { return (nrp % 32 == 0) ? nrp + 16 : nrp; }
 // THREADS: workgroup size (>= 256); MT: row tiles per wavefront (THREADS / 64 * MT * 16 >= nrp); DB: the next panel's
 // multipliers are fetched while the current panel is applied (twice the registers).
 template <int THREADS, int MT, bool DB>
-__global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_rhs_kernel(RhsArgs p) {
     extern __shared__ __align__(16) double sm[];
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -339,7 +338,6 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
     double *u12s = blk + (size_t)kNB * ld;  // [16][16]: u12s[row * 16 + col]
     double *linv = u12s + kNB * kNB;        // [16][16]
     int *tmeta = (int *)(linv + kNB * kNB); // tcount, trow[32], tsrc[32]
-    double *stage = linv + kNB * kNB + (2 * kMaxTouched + 4) / 2;  // kStageDoubles: Gamma's rows at the start, U11 blocks at the end
     const bool bad = p.failed[li] != 0;
     if (p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
     const long long ER = (long long)p.nr * p.nrhs;
@@ -358,7 +356,7 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             const int t = wv + NW * u;
-            if (t < npan && t != pn) {
+            if (t < npan && t != pn && !((MPCX_RHS_ABLATE & 64) && pn > 0)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     dst[u][q] = A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
@@ -373,8 +371,6 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
         if (tid < kNB * kNB) m_linv = mt[tid];
         if (tid < 1 + 2 * kMaxTouched) m_int = ((const int *)(mt + kMetaInts))[tid];
     };
-    fetch_meta(0);
-    fetch_multipliers(0, lb[0]);
     // The block: 16 columns of the right-hand side, rows beyond nr and columns beyond nrhs zero.
     if (MPCX_RHS_ABLATE & 1) {
     } else if (p.Q == nullptr) {
@@ -384,48 +380,44 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
         }
     } else {
         // Gamma^T blockdiag(Q) (controller.rs:96, M^T W4): column c = g r + a2, row k is sum_a Gamma[g r + a][k] Q[a2][a]
-        // (Q stored column-major: Q[a2 * r + a]).  Gamma is (f r) x (v m) column-major, so the rows [lo, hi) of Gamma
-        // that the block's columns touch are one contiguous run per unknown k: kc unknowns at a time go through LDS.
+        // (Q stored column-major: Q[a2 * r + a]).  The block's 16 columns touch the rows [lo, hi) of Gamma, a contiguous
+        // run per unknown k of the column-major (f r) x (v m) array.  Per tile of 16 unknowns the block is the product
+        // D[column][unknown] = sum_j S[column][j] Gamma[lo + j][unknown], S the selection of Q's entries (zero where row
+        // lo + j lies outside the column's weight block): on the matrix cores, Gamma read straight from memory.
         const int r = p.r, lo = (c0 / r) * r;
         int hi = ((c0 + kNB - 1) / r + 1) * r;
         if (hi > p.nrhs) hi = p.nrhs;
-        const int w = hi - lo, kc = p.kc;
+        const int w = hi - lo, ns = (w + 3) / 4;
         const bool q_lds = r * r <= kNB * kNB;  // the weight block rides in LDS (the U12 buffer is idle until the panels start)
-        if (q_lds)
+        if (q_lds) {
             for (int e = tid; e < r * r; e += THREADS) u12s[e] = p.Q[e];
+            __syncthreads();
+        }
         const double *qw = q_lds ? u12s : p.Q;
-        constexpr int PER = (kStageDoubles + THREADS - 1) / THREADS;
-        double greg[PER];
-        auto fetch_gamma = [&](int kb) {
+        const int cc = c0 + l15, g = cc / r, a2 = cc - g * r, joff = lo - g * r;  // A operand: column lane & 15
+        constexpr int SC = 12;  // steps of four rows of Gamma in flight per tile
+        for (int t = wv; t < npan; t += NW) {
+            const int k = t * kNB + l15;  // B operand: unknown lane & 15
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int s0 = 0; s0 < ns; s0 += SC) {
+                double gb[SC], qa[SC];
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int e = tid + u * THREADS, kk = e / w, j = e - kk * w, k = kb + kk;
-                greg[u] = (e < kc * w && k < p.nr) ? p.R[elem_index(b, (long long)k * p.nrhs + lo + j, ER, p.W)] : 0.0;
-            }
-        };
-        fetch_gamma(0);
-        for (int kb = 0; kb < nrp; kb += kc) {
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < PER; ++u)
-                if (tid + u * THREADS < kc * w) stage[tid + u * THREADS] = greg[u];
-            __syncthreads();
-            if (kb + kc < nrp) fetch_gamma(kb + kc);
-            for (int e = tid; e < kc * kNB; e += THREADS) {
-                const int c = e / kc, kk = e - c * kc, k = kb + kk;
-                if (k >= nrp) continue;
-                double v = 0.0;
-                if (k < p.nr && c0 + c < p.nrhs) {
-                    const int g = (c0 + c) / r, a2 = (c0 + c) - g * r;
-                    const double *row = stage + kk * w + (g * r - lo), *qrow = qw + a2 * r;
-#pragma unroll 4
-                    for (int a = 0; a < r; ++a) v += row[a] * qrow[a];
+                for (int u = 0; u < SC; ++u) {
+                    const int jj = 4 * (s0 + u) + kq, ja = jj + joff;
+                    gb[u] = (k < p.nr && jj < w) ? p.R[elem_index(b, (long long)k * p.nrhs + lo + jj, ER, p.W)] : 0.0;
+                    qa[u] = (cc < p.nrhs && jj < w && ja >= 0 && ja < r) ? qw[a2 * r + ja] : 0.0;
                 }
-                blk[c * ld + k] = v;
+#pragma unroll
+                for (int u = 0; u < SC; ++u)
+                    if (s0 + u < ns) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[u], gb[u], acc, 0, 0, 0);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) blk[(kq + 4 * q) * ld + t * kNB + l15] = acc[q];
         }
         __syncthreads();  // the weight block leaves the U12 buffer
     }
+    fetch_meta(0);
+    fetch_multipliers(0, lb[0]);
     auto panel_step = [&](int pn, double(&cur)[MT][4], double(&nxt)[MT][4]) {
         if ((MPCX_RHS_ABLATE & 2) && pn >= 0) return;
         const int k0 = pn * kNB;
@@ -441,7 +433,7 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
         const int ntouched = tmeta[0];
         double uv = 0.0, moved = 0.0;
         const int i = tid & 15, c = (tid >> 4) & 15;
-        if (tid < kNB * kNB) {
+        if (tid < kNB * kNB && !(MPCX_RHS_ABLATE & 32)) {
 #pragma unroll 4
             for (int k = 0; k < kNB; ++k) uv = fma(linv[i * kNB + k], blk[c * ld + tmeta[1 + kMaxTouched + k]], uv);
             if (kNB + i < ntouched) moved = blk[(size_t)c * ld + tmeta[1 + kMaxTouched + kNB + i]];
@@ -473,6 +465,12 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
         }
         if (!DB && pn + 1 < npan) fetch_multipliers(pn + 1, cur);
     };
+    double un[4];  // this wavefront's next U11^-1 operand for the last step
+    auto fetch_uinv = [&](int pn) {
+        const double *ui = meta + (size_t)pn * kMetaDoubles + kNB * kNB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) un[q] = ui[l15 * kNB + kq + 4 * q];
+    };
     if (DB) {
         int pn = 0;
         for (; pn + 1 < npan; pn += 2) {
@@ -483,17 +481,19 @@ __global__ __launch_bounds__(THREADS) void lu_rhs_kernel(RhsArgs p) {
     } else {
         for (int pn = 0; pn < npan; ++pn) panel_step(pn, lb[0], lb[0]);
     }
+    if (wv < npan) fetch_uinv(wv);
     __syncthreads();
-    // x_p = U11_p^-1 y_p per panel, in place: one 16x16x16 product per panel, panels dealt to the wavefronts
+    // x_p = U11_p^-1 y_p per panel, in place: one 16x16x16 product per panel, panels dealt to the wavefronts (each
+    // further inverse is fetched while its predecessor is applied)
     for (int pn = wv; pn < npan && !(MPCX_RHS_ABLATE & 8); pn += NW) {
-        const double *ui = meta + (size_t)pn * kMetaDoubles + kNB * kNB;
-        d4 x = {0.0, 0.0, 0.0, 0.0};
         double ua[4], yb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ua[q] = ui[l15 * kNB + kq + 4 * q];              // A operand: U11^-1[i = lane & 15][k]
+            ua[q] = un[q];                                   // A operand: U11^-1[i = lane & 15][k]
             yb[q] = blk[l15 * ld + pn * kNB + kq + 4 * q];   // B operand: y[k][column lane & 15]
         }
+        if (pn + NW < npan) fetch_uinv(pn + NW);
+        d4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[q], yb[q], x, 0, 0, 0);
 #pragma unroll
@@ -530,7 +530,7 @@ int launch_rhs_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
 }
 
 size_t rhs_lds_bytes(int nrp) {
-    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2 + kStageDoubles) * sizeof(double);
+    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2) * sizeof(double);
 }
 
 constexpr int kSmallRows = 256;  // up to here the 256-thread panel kernel
@@ -571,12 +571,6 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         hipError_t e = hipFuncSetAttribute((const void *)lu_block_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    int kc = 0;
-    if (Q != nullptr) {  // rows of Gamma a block of 16 columns can touch: 16 + 2 (r - 1) at most
-        const int wmax = (2 * r + 14 < nrhs) ? 2 * r + 14 : nrhs;
-        kc = kStageDoubles / (wmax > 0 ? wmax : 1);
-        if (kc > nrp) kc = nrp;
-    }
     for (long long first = 0; first < batch; first += chunk) {
         const long long count = (batch - first < chunk) ? batch - first : chunk;
         int *failed = (int *)(ws + (size_t)count * nrp * nrp);  // behind the matrices of this launch
@@ -592,7 +586,7 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         else hipLaunchKernelGGL((lu_block_kernel<512, true>), dim3((unsigned)count), dim3(512), lds_bytes, s, la);
         const long long total = count * (long long)((nrhs + kNB - 1) / kNB), per_xcd = (total + 7) / 8;
         if (per_xcd * 8 > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-        RhsArgs ra{ws, failed, meta, R, Q, X, info, first, count, W, total, nr, nrhs, r, nrp, negate, rhs_ld(nrp), kc};
+        RhsArgs ra{ws, failed, meta, R, Q, X, info, first, count, W, total, nr, nrhs, r, nrp, negate, rhs_ld(nrp)};
         if (total > 0) {
             const int rc = launch_rhs_any(ra, rhs_bytes, s);
             if (rc != 0) return rc;
