@@ -34,6 +34,7 @@ namespace mpcx {
 namespace {
 
 using d4 = __attribute__((ext_vector_type(4))) double;
+
 constexpr int kNB = 16;
 constexpr int kMaxTouched = 2 * kNB;
 
@@ -299,9 +300,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_block_kern
 
 // ---- right-hand sides: one workgroup per instance and block of 16 columns, the block resident in LDS ----
 struct RhsArgs {
-    const double *ws;    // as LuArgs::ws, after lu_block_kernel: multipliers, and U11 in the diagonal blocks
-    const int *failed;
-    const double *meta;
+    double *ws;          // as LuArgs::ws; for the right-hand sides: after the panels, multipliers and U11 in the diagonal blocks
+    int *failed;
+    double *meta;
     const double *R, *Q; // Q != nullptr: R is Gamma (fr x nr per instance) and the right-hand side is Gamma^T blockdiag(Q)
     double *X;
     int *info;
@@ -319,8 +320,14 @@ int rhs_ld(int nrp) { return (nrp % 32 == 0) ? nrp + 16 : nrp; }
 
 // THREADS: workgroup size (>= 256); MT: row tiles per wavefront (THREADS / 64 * MT * 16 >= nrp); DB: the next panel's
 // multipliers are fetched while the current panel is applied (twice the registers).
-template <int THREADS, int MT, bool DB>
-__global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_rhs_kernel(RhsArgs p) {
+//
+// FACTOR: the same machinery run over H's own column blocks, left-looking, one workgroup per instance: block j is
+// loaded, the panels 0..j-1 are applied to it exactly as to a block of right-hand sides, then it is factored in LDS as
+// panel j (pivot search, exchanges, multipliers for every row outside the pivot block) and written back with what the
+// later blocks need.  H's columns are read and written once; what is streamed per block are the multipliers of the
+// panels before it, half the bytes of a right-looking sweep over the trailing columns and reads only.
+template <int THREADS, int MT, bool DB, bool FACTOR>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kernel(RhsArgs p) {  // at most 16 wavefronts (LDS slots)
     extern __shared__ __align__(16) double sm[];
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -328,18 +335,18 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_rhs_kernel
     // Workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (instance, block) pairs, so
     // that the blocks of one instance, which read the same multipliers, share one L2.
     const long long per_xcd = (p.total + 7) / 8;
-    const long long item = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || item >= p.total) return;
-    const long long li = item / nblk;
-    const int bk = (int)(item - li * nblk), c0 = bk * kNB;
+    const long long item = FACTOR ? (long long)blockIdx.x : (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (!FACTOR && ((blockIdx.x >> 3) >= per_xcd || item >= p.total)) return;
+    const long long li = FACTOR ? item : item / nblk;
+    const int bk = FACTOR ? 0 : (int)(item - li * nblk), c0 = bk * kNB;
     const long long b = p.first + li;
-    const double *A = p.ws + (size_t)li * nrp * nrp;
+    double *A = p.ws + (size_t)li * nrp * nrp;
     double *blk = sm;                       // [16][ld]: blk[c * ld + row]
     double *u12s = blk + (size_t)kNB * ld;  // [16][16]: u12s[row * 16 + col]
     double *linv = u12s + kNB * kNB;        // [16][16]
     int *tmeta = (int *)(linv + kNB * kNB); // tcount, trow[32], tsrc[32]
-    const bool bad = p.failed[li] != 0;
-    if (p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
+    const bool bad = !FACTOR && p.failed[li] != 0;
+    if (!FACTOR && p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
     const long long ER = (long long)p.nr * p.nrhs;
     if (bad) {  // uniform over the workgroup
         for (int e = tid; e < kNB * p.nr; e += THREADS) {
@@ -350,9 +357,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_rhs_kernel
     }
     const int kq = lane >> 4, l15 = lane & 15;
     const int lofs = kq * nrp + l15;  // a lane's place in a tile of multipliers: + panel's first column, + 4 q columns, + r0
-    const double *meta = p.meta + (size_t)li * npan * kMetaDoubles;
+    double *meta = p.meta + (size_t)li * npan * kMetaDoubles;
     double lb[DB ? 2 : 1][MT][4];
-    auto fetch_multipliers = [&](int pn, double(&dst)[MT][4]) {
+    auto fetch_multipliers = [&](int pn, double(&dst)[MT][4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             const int t = wv + NW * u;
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_rhs_kernel
         if (tid < 1 + 2 * kMaxTouched) m_int = ((const int *)(mt + kMetaInts))[tid];
     };
     // The block: 16 columns of the right-hand side, rows beyond nr and columns beyond nrhs zero.
-    if (MPCX_RHS_ABLATE & 1) {
+    if (FACTOR || (MPCX_RHS_ABLATE & 1)) {
     } else if (p.Q == nullptr) {
         for (int e = tid; e < kNB * nrp; e += THREADS) {
             const int c = e / nrp, row = e - c * nrp;
@@ -416,15 +423,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_rhs_kernel
         }
         __syncthreads();  // the weight block leaves the U12 buffer
     }
-    fetch_meta(0);
-    fetch_multipliers(0, lb[0]);
-    auto panel_step = [&](int pn, double(&cur)[MT][4], double(&nxt)[MT][4]) {
+    auto panel_step = [&](int pn, int upto, double(&cur)[MT][4], double(&nxt)[MT][4]) __attribute__((always_inline)) {
         if ((MPCX_RHS_ABLATE & 2) && pn >= 0) return;
         const int k0 = pn * kNB;
         if (tid < kNB * kNB) linv[tid] = m_linv;
         if (tid < 1 + 2 * kMaxTouched) tmeta[tid] = m_int;
         __syncthreads();  // also orders the previous panel's updates (and the initial load) before the reads below
-        if (pn + 1 < npan) {
+        if (pn + 1 < upto) {
             fetch_meta(pn + 1);
             if (DB) fetch_multipliers(pn + 1, nxt);
         }
@@ -463,24 +468,151 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_rhs_kernel
                 for (int q = 0; q < 4; ++q) blk[cofs + 4 * q * ld + r0] = acc[q];
             }
         }
-        if (!DB && pn + 1 < npan) fetch_multipliers(pn + 1, cur);
+        if (!DB && pn + 1 < upto) fetch_multipliers(pn + 1, cur);
     };
+    // the panels [0, upto) applied to the block in LDS
+    auto apply_panels = [&](int upto) __attribute__((always_inline)) {
+        if (upto <= 0) return;
+#pragma unroll
+        for (int u = 0; u < MT; ++u)  // every slot defined here: nothing of the previous block's multipliers stays live
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lb[0][u][q] = lb[DB ? 1 : 0][u][q] = 0.0;
+        fetch_meta(0);
+        fetch_multipliers(0, lb[0]);
+        if (DB) {
+            int pn = 0;
+            for (; pn + 1 < upto; pn += 2) {
+                panel_step(pn, upto, lb[0], lb[DB ? 1 : 0]);
+                panel_step(pn + 1, upto, lb[DB ? 1 : 0], lb[0]);
+            }
+            if (pn < upto) panel_step(pn, upto, lb[0], lb[DB ? 1 : 0]);
+        } else {
+            for (int pn = 0; pn < upto; ++pn) panel_step(pn, upto, lb[0], lb[0]);
+        }
+    };
+    if constexpr (FACTOR) {
+        double *red_val = (double *)(tmeta + 2 * kMaxTouched + 4);  // [NW]
+        int *red_idx = (int *)(red_val + NW);                       // [NW]
+        int *ipiv = red_idx + NW;                                   // [16]
+        double *uinv = u12s;
+        int *tcount = tmeta, *trow = tmeta + 1, *tsrc = tmeta + 1 + kMaxTouched;
+        for (int j = 0; j < npan; ++j) {
+            const int k0 = j * kNB;
+            double *gcol = A + (size_t)k0 * nrp;  // the block's 16 columns are one contiguous run of the workspace
+            for (int e = tid; e < kNB * nrp; e += THREADS) {
+                const int c = e / nrp, row = e - c * nrp;
+                blk[c * ld + row] = gcol[e];
+            }
+            apply_panels(j);
+            __syncthreads();
+            // panel j in LDS: column by column, pivot searched in rows >= k0 + jc, every row outside the pivot block reduced
+            for (int jc = 0; jc < kNB; ++jc) {
+                double *col = blk + jc * ld;
+                const int kk = k0 + jc;
+                double best = -1.0;
+                int bi = kk;
+                for (int rr = kk + tid; rr < nrp; rr += THREADS) {
+                    double a = fabs(col[rr]);
+                    if (!(a == a)) a = INFINITY;  // a NaN must be chosen (and fail), not skipped
+                    if (a > best) { best = a; bi = rr; }
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ob = __shfl_xor(best, off);
+                    const int oi = __shfl_xor(bi, off);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (lane == 0) { red_val[wv] = best; red_idx[wv] = bi; }
+                __syncthreads();
+                best = red_val[0];
+                bi = red_idx[0];
+#pragma unroll
+                for (int w2 = 1; w2 < NW; ++w2) {
+                    const double ob = red_val[w2];
+                    const int oi = red_idx[w2];
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (!(best > 0.0) || !isfinite(best)) {  // uniform over the workgroup
+                    if (tid == 0) p.failed[li] = 1;
+                    return;
+                }
+                if (tid < kNB) {
+                    const double t = blk[tid * ld + kk];
+                    blk[tid * ld + kk] = blk[tid * ld + bi];
+                    blk[tid * ld + bi] = t;
+                    if (tid == 0) ipiv[jc] = bi;
+                }
+                __syncthreads();
+                const double inv = 1.0 / col[kk];
+                for (int rr = tid; rr < nrp; rr += THREADS) {
+                    if (rr >= k0 && rr <= kk) continue;  // the panel's earlier pivot rows keep their entry: it belongs to U11
+                    const double l = col[rr] * inv;
+                    col[rr] = l;
+#pragma unroll
+                    for (int jj = 1; jj < kNB; ++jj)
+                        if (jc + jj < kNB) blk[(jc + jj) * ld + rr] -= l * blk[(jc + jj) * ld + kk];
+                }
+                __syncthreads();
+            }
+            // what the later blocks and the right-hand sides need of this panel
+            if (tid < kNB) {  // column tid of L11^-1 by forward substitution on a unit vector, kept in LDS as it grows
+#pragma unroll 1
+                for (int i = 0; i < kNB; ++i) {
+                    double sacc = (i == tid) ? 1.0 : 0.0;
+#pragma unroll 5
+                    for (int q = 0; q < i; ++q) sacc -= blk[q * ld + k0 + i] * linv[q * kNB + tid];
+                    linv[i * kNB + tid] = sacc;
+                }
+            }
+            if (tid >= 128 && tid < 128 + kNB) {  // column of U11^-1 by backward substitution, kept in LDS as it grows
+                const int jc = tid - 128;
+#pragma unroll 1
+                for (int i = kNB - 1; i >= 0; --i) {
+                    double sacc = (i == jc) ? 1.0 : 0.0;
+#pragma unroll 5
+                    for (int q = kNB - 1; q > i; --q) sacc -= blk[q * ld + k0 + i] * uinv[q * kNB + jc];
+                    uinv[i * kNB + jc] = sacc / blk[i * ld + k0 + i];
+                }
+            }
+            if (tid == 64) {  // net effect of the 16 exchanges: which rows end up with whose old content
+                int n = kNB;
+                for (int q = 0; q < kNB; ++q) { trow[q] = k0 + q; tsrc[q] = k0 + q; }
+                for (int jc = 0; jc < kNB; ++jc) {
+                    const int bq = ipiv[jc];
+                    if (bq == k0 + jc) continue;
+                    int ib = -1;
+                    for (int q = 0; q < n; ++q)
+                        if (trow[q] == bq) ib = q;
+                    if (ib < 0) { ib = n; trow[n] = bq; tsrc[n] = bq; ++n; }
+                    const int t = tsrc[jc];
+                    tsrc[jc] = tsrc[ib];
+                    tsrc[ib] = t;
+                }
+                *tcount = n;
+            }
+            __syncthreads();
+            for (int e = tid; e < kNB * nrp; e += THREADS) {
+                const int c = e / nrp, row = e - c * nrp;
+                gcol[e] = blk[c * ld + row];
+            }
+            {
+                double *mt = meta + (size_t)j * kMetaDoubles;
+                if (tid < kNB * kNB) { mt[tid] = linv[tid]; mt[kNB * kNB + tid] = uinv[tid]; }
+                if (tid < 1 + 2 * kMaxTouched) ((int *)(mt + kMetaInts))[tid] = tmeta[tid];
+            }
+            // the next blocks stream this panel back through the vector cache: make the stores visible device-wide and
+            // drop what the cache holds of these lines from the block's load
+            __threadfence();
+            __syncthreads();
+        }
+        return;
+    }
+    apply_panels(npan);
     double un[4];  // this wavefront's next U11^-1 operand for the last step
     auto fetch_uinv = [&](int pn) {
         const double *ui = meta + (size_t)pn * kMetaDoubles + kNB * kNB;
 #pragma unroll
         for (int q = 0; q < 4; ++q) un[q] = ui[l15 * kNB + kq + 4 * q];
     };
-    if (DB) {
-        int pn = 0;
-        for (; pn + 1 < npan; pn += 2) {
-            panel_step(pn, lb[0], lb[DB ? 1 : 0]);
-            panel_step(pn + 1, lb[DB ? 1 : 0], lb[0]);
-        }
-        if (pn < npan) panel_step(pn, lb[0], lb[DB ? 1 : 0]);
-    } else {
-        for (int pn = 0; pn < npan; ++pn) panel_step(pn, lb[0], lb[0]);
-    }
     if (wv < npan) fetch_uinv(wv);
     __syncthreads();
     // x_p = U11_p^-1 y_p per panel, in place: one 16x16x16 product per panel, panels dealt to the wavefronts (each
@@ -507,32 +639,38 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_rhs_kernel
     }
 }
 
-template <int THREADS, int MT, bool DB>
-int launch_rhs(const RhsArgs &ra, size_t lds, hipStream_t s) {
+template <int THREADS, int MT, bool DB, bool FACTOR>
+int launch_apply(const RhsArgs &ra, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)lu_rhs_kernel<THREADS, MT, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)lu_apply_kernel<THREADS, MT, DB, FACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const long long per_xcd = (ra.total + 7) / 8;
-    hipLaunchKernelGGL((lu_rhs_kernel<THREADS, MT, DB>), dim3((unsigned)(per_xcd * 8)), dim3(THREADS), lds, s, ra);
+    const long long grid = FACTOR ? ra.count : (ra.total + 7) / 8 * 8;
+    hipLaunchKernelGGL((lu_apply_kernel<THREADS, MT, DB, FACTOR>), dim3((unsigned)grid), dim3(THREADS), lds, s, ra);
     return 0;
 }
 
 constexpr int kRhsMaxRows = 8 * 10 * kNB;  // the widest variant: 8 wavefronts x 10 tiles
 
-int launch_rhs_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
+template <bool FACTOR>
+int launch_apply_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
     const int npan = ra.nrp / kNB;
-    if (npan <= 8) return launch_rhs<256, 2, true>(ra, lds, s);
-    if (npan <= 16) return launch_rhs<256, 4, true>(ra, lds, s);
-    if (npan <= 32) return launch_rhs<512, 4, true>(ra, lds, s);
-    if (npan <= 56) return launch_rhs<512, 7, true>(ra, lds, s);
-    return launch_rhs<512, 10, false>(ra, lds, s);
+    constexpr bool DB = true;
+    if (npan <= 8) return launch_apply<256, 2, DB, FACTOR>(ra, lds, s);
+    if (npan <= 16) return launch_apply<256, 4, DB, FACTOR>(ra, lds, s);
+    if (npan <= 32) return launch_apply<512, 4, DB, FACTOR>(ra, lds, s);
+    if (npan <= 56) return launch_apply<512, 7, DB, FACTOR>(ra, lds, s);
+    return launch_apply<512, 10, false, FACTOR>(ra, lds, s);
 }
 
-size_t rhs_lds_bytes(int nrp) {
-    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2) * sizeof(double);
+size_t rhs_lds_bytes(int nrp) {  // block, U12 / U11^-1, L11^-1, exchange lists, then the panel factorization's reduction slots and pivots
+    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2 + 16) * sizeof(double) + sizeof(int) * (16 + kNB);
 }
 
+#ifndef MPCX_LU_LEFT_FROM
+#define MPCX_LU_LEFT_FROM 257  // rows from which H is factored left-looking (lu_apply_kernel<..., true>); below, right-looking
+#endif
+bool left_looking(int nrp) { return nrp >= MPCX_LU_LEFT_FROM; }
 constexpr int kSmallRows = 256;  // up to here the 256-thread panel kernel
 int lu_threads(int nrp) { return nrp <= kSmallRows ? 256 : 512; }
 
@@ -582,13 +720,20 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         PackArgs pa{H, ws, first, count, W, nr, nrp};
         hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa);
         LuArgs la{ws, failed, count, nrp, meta};
-        if (lu_threads(nrp) == 256) hipLaunchKernelGGL((lu_block_kernel<256, false>), dim3((unsigned)count), dim3(256), lds_bytes, s, la);
-        else hipLaunchKernelGGL((lu_block_kernel<512, true>), dim3((unsigned)count), dim3(512), lds_bytes, s, la);
+        RhsArgs ra{ws, failed, meta, R, Q, X, info, first, count, W, 0, nr, nrhs, r, nrp, negate, rhs_ld(nrp)};
+        if (left_looking(nrp)) {
+            const int rc = launch_apply_any<true>(ra, rhs_bytes, s);
+            if (rc != 0) return rc;
+        } else if (lu_threads(nrp) == 256) {
+            hipLaunchKernelGGL((lu_block_kernel<256, false>), dim3((unsigned)count), dim3(256), lds_bytes, s, la);
+        } else {
+            hipLaunchKernelGGL((lu_block_kernel<512, true>), dim3((unsigned)count), dim3(512), lds_bytes, s, la);
+        }
         const long long total = count * (long long)((nrhs + kNB - 1) / kNB), per_xcd = (total + 7) / 8;
         if (per_xcd * 8 > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-        RhsArgs ra{ws, failed, meta, R, Q, X, info, first, count, W, total, nr, nrhs, r, nrp, negate, rhs_ld(nrp)};
+        ra.total = total;
         if (total > 0) {
-            const int rc = launch_rhs_any(ra, rhs_bytes, s);
+            const int rc = launch_apply_any<false>(ra, rhs_bytes, s);
             if (rc != 0) return rc;
         }
         e = hipGetLastError();

@@ -103,7 +103,8 @@ def test_reference_horizon_rows_in_registers(ctx, il, batch):
         assert rel_fro(u[b], -np.linalg.solve(H[b], fv[b])) <= 1e-11 * cond, f"solve of instance {b}"
 
 
-@pytest.mark.parametrize("vm,m,fr,r,il", [(65, 1, 70, 1, 1), (100, 2, 150, 3, 1), (130, 1, 140, 1, 0), (200, 4, 600, 12, 1), (48, 1, 500, 1, 1)])
+@pytest.mark.parametrize("vm,m,fr,r,il", [(65, 1, 70, 1, 1), (100, 2, 150, 3, 1), (130, 1, 140, 1, 0), (200, 4, 600, 12, 1), (48, 1, 500, 1, 1),
+                                          (300, 2, 320, 2, 1), (530, 1, 530, 1, 1), (904, 2, 1356, 3, 1)])
 def test_large_systems_blocked_solver(ctx, vm, m, fr, r, il):
     """Beyond 64 unknowns (or right-hand sides that do not fit LDS): the blocked solver on a device workspace."""
     rng = np.random.default_rng(vm + fr)
@@ -127,12 +128,16 @@ def test_large_systems_blocked_solver(ctx, vm, m, fr, r, il):
     assert rel_fro(gain, want) <= 1e-11 * cond
 
 
-def test_large_singular_is_flagged(ctx):
+@pytest.mark.parametrize("vm", [96, 400])
+def test_large_singular_is_flagged(ctx, vm):
     rng = np.random.default_rng(8)
-    batch, vm = 4, 96
+    batch = 4
     H = rng.standard_normal((batch, vm, vm)) + 10 * np.eye(vm)
     H[1, :, 40] = 0.0
-    H[2, 70, :] = H[2, 3, :]                          # two equal rows: an exactly zero pivot late in the elimination
+    if vm == 96:
+        H[2, 70, :] = H[2, 3, :]                      # two equal rows: an exactly zero pivot late in the elimination
+    else:
+        H[2, vm - 30, :] = 0.0                        # a zero row stays zero through every update: the last pivot is exactly zero
     fv = rng.standard_normal((batch, vm))
     u, info = ctx.qp_solve(H, fv, 1)
     assert list(info) == [0, 1, 1, 0]
