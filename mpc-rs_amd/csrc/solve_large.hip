@@ -7,27 +7,28 @@
 // yet used as a pivot; a zero or non-finite pivot marks the instance failed (the reference's "Matrix inversion failed").
 //
 // Algorithm, per panel of kNB = 16 columns starting at k0:
-//   1. the whole panel (all rows, 16 columns) is loaded into LDS and factored there: for column j the pivot is searched
-//      in rows >= k0 + j, exchanged into row k0 + j, and every other row outside the panel's pivot block, the rows
-//      above k0 included, gets its multiplier l = a / pivot and is reduced in the remaining panel columns.
-//      Eliminating above as well as below (block Gauss-Jordan) means there is no backward sweep over the matrix.
-//   2. each wavefront takes blocks of 16 columns to the right (the rest of H; a block of right-hand sides is treated
-//      the same way by its own workgroup): it applies the
-//      panel's row exchanges, forms U12 = L11^-1 T for the 16 pivot rows (one 16x16x16 product with the inverse of the
-//      panel's unit lower triangle) and subtracts (multipliers) x U12 from every other 16-row tile.  Products are
-//      computed transposed, so that a lane's four accumulators are four columns of one row and a tile is read and
-//      written as 128-byte runs of the column-major workspace.
-// What remains is block diagonal with the 16x16 upper triangles U11 of the panels.
+//   1. the whole panel (all rows, 16 columns) is factored in LDS: for column j the pivot is searched in rows >= k0 + j,
+//      exchanged into row k0 + j, and every other row outside the panel's pivot block, the rows above k0 included,
+//      gets its multiplier l = a / pivot and is reduced in the remaining panel columns.  Eliminating above as well as
+//      below (block Gauss-Jordan) means there is no backward sweep over the matrix.
+//   2. a block of 16 other columns (of H, or of right-hand sides) follows the panel: the panel's row exchanges,
+//      U12 = L11^-1 T for the 16 pivot rows (the inverse of the panel's unit lower triangle is formed once per panel),
+//      and (multipliers) x U12 subtracted from every other 16-row tile on the matrix cores.  Products are computed
+//      transposed, so that a lane's four accumulators are four columns of one row.
+// What remains is block diagonal with the 16x16 upper triangles U11 of the panels; x_p = U11_p^-1 y_p finishes.
 //
-// Two kernels.  lu_block_kernel runs the panels over H alone (its trailing columns) and leaves, per panel, what a
-// right-hand side needs to follow: the multipliers (in place, in the panel's columns), the net row exchanges and
-// L11^-1.  lu_rhs_kernel then gives every block of 16 right-hand-side columns to a workgroup of its own, which keeps
-// the block in LDS through all panels (exchanges, U12, the rank-16 update of every other row tile on the matrix
-// cores, multipliers streamed from memory), solves the U11 blocks and writes the result in the caller's layout.  The
-// block is formed from the caller's arrays as it is loaded (Gamma^T blockdiag(Q) included), so a right-hand side is
-// read once and its solution written once, and never enters the workspace; the workgroups of one instance read the
-// same multipliers at about the same time (L2 / Infinity Cache hits).  HBM traffic of the elimination: one pass over
-// H's trailing columns per panel, plus one pass over the right-hand sides and one over the result.
+// Kernels.  H is factored first, one workgroup per instance, and leaves per panel what a block of columns needs to
+// follow it: the multipliers (in place, in the panel's columns), the net row exchanges, L11^-1 and U11^-1.
+//   - up to 256 rows: lu_block_kernel, right-looking (after each panel the wavefronts sweep the trailing columns of H
+//     in the workspace);
+//   - beyond: lu_apply_kernel<..., FACTOR = true>, left-looking (column block j is loaded into LDS, the panels before
+//     it are applied with their multipliers streamed from the workspace, then it is factored and written back): H's
+//     columns are read and written once, and the streamed multipliers are half the bytes of the trailing sweeps.
+// lu_apply_kernel<..., false> then gives every block of 16 right-hand-side columns to a workgroup of its own, which
+// keeps the block in LDS through all panels, applies U11^-1 and writes the result in the caller's layout.  The block is
+// formed from the caller's arrays as it is loaded (Gamma^T blockdiag(Q) included), so a right-hand side is read once
+// and its solution written once, and never enters the workspace; the workgroups of one instance run on one XCD and
+// read the same multipliers at about the same time (L2 hits).
 #include "mpcx_internal.h"
 
 namespace mpcx {
@@ -69,12 +70,11 @@ __global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p) {
 }
 
 // ---- factor / eliminate: one workgroup per instance ----
-// THREADS = 512 with the pipelined column sweep for large systems (HBM bound); 256 and a plain sweep for small ones,
-// whose time goes into the barriers of the panel factorization: fewer registers and a smaller workgroup let several
-// instances share a CU.
-template <int THREADS, bool PIPE>
-__global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_block_kernel(LuArgs p) {
-    constexpr int kThreads = THREADS, kWaves = THREADS / 64;
+// Right-looking, for systems of up to kSmallRows rows: their time goes into the barriers of the panel factorization, and
+// a workgroup of 256 threads within 128 registers lets four instances share a CU.  (Larger systems are factored
+// left-looking by lu_apply_kernel<..., true>, which moves half the bytes.)
+constexpr int kThreads = 256, kWaves = kThreads / 64;
+__global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
     extern __shared__ __align__(16) double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nrp = p.nrp;
@@ -230,57 +230,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_block_kern
             for (int q = 0; q < 4; ++q) A[(size_t)(c0 + (lane & 15)) * nrp + k0 + (lane >> 4) + 4 * q] = u12[q];
             // every other 16-row tile: C^T -= U12^T L^T.  A operand [i' = column][k] = U12[k][column] is u12 as it stands.
             const d4 nu = -u12;
-            // Tiles are taken four at a time; the next four are fetched before the current four are stored, so the
-            // loads of a group are in flight while the previous group is computed and written back.
-            const int pidx = k0 / kNB, nt = nrp / kNB - 1, nt4 = nt & ~3;
+            const int pidx = k0 / kNB, nt = nrp / kNB - 1;
             double *cbase = A + (size_t)(c0 + (lane >> 4)) * nrp + (lane & 15);  // + r0, + 4 q columns
             auto row0 = [&](int t) { return (t < pidx ? t : t + 1) * kNB; };
-            d4 buf[4], nbuf[4];
-            if (!PIPE) {
-                for (int t = 0; t < nt; ++t) {
-                    const int r0 = row0(t);
-                    d4 acc;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = cbase[(size_t)(4 * q) * nrp + r0];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double lb = panel[(size_t)((lane >> 4) + 4 * q) * nrp + r0 + (lane & 15)];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb, acc, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cbase[(size_t)(4 * q) * nrp + r0] = acc[q];
-                }
-                continue;
-            }
-            if (nt4 > 0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) buf[u][q] = cbase[(size_t)(4 * q) * nrp + row0(u)];
-            }
-            for (int t = 0; t < nt4; t += 4) {
-                const int tn = (t + 4 < nt4) ? t + 4 : t;  // the last round re-reads its own tiles; the values are not used
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) nbuf[u][q] = cbase[(size_t)(4 * q) * nrp + row0(tn + u)];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r0 = row0(t + u);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const double lb = panel[(size_t)((lane >> 4) + 4 * q) * nrp + r0 + (lane & 15)];
-                        buf[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb, buf[u], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cbase[(size_t)(4 * q) * nrp + row0(t + u)] = buf[u][q];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) buf[u] = nbuf[u];
-            }
-            for (int t = nt4; t < nt; ++t) {
+            for (int t = 0; t < nt; ++t) {
                 const int r0 = row0(t);
                 d4 acc;
 #pragma unroll
@@ -667,17 +620,12 @@ size_t rhs_lds_bytes(int nrp) {  // block, U12 / U11^-1, L11^-1, exchange lists,
     return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2 + 16) * sizeof(double) + sizeof(int) * (16 + kNB);
 }
 
-#ifndef MPCX_LU_LEFT_FROM
-#define MPCX_LU_LEFT_FROM 257  // rows from which H is factored left-looking (lu_apply_kernel<..., true>); below, right-looking
-#endif
-bool left_looking(int nrp) { return nrp >= MPCX_LU_LEFT_FROM; }
-constexpr int kSmallRows = 256;  // up to here the 256-thread panel kernel
-int lu_threads(int nrp) { return nrp <= kSmallRows ? 256 : 512; }
+constexpr int kSmallRows = 256;  // up to here H is factored right-looking by lu_block_kernel, beyond left-looking
+bool left_looking(int nrp) { return nrp > kSmallRows; }
 
-size_t lu_lds_bytes(int nrp) {
-    const int waves = lu_threads(nrp) / 64;
-    size_t d = (size_t)kNB * nrp + 2 * kNB * kNB + waves * kNB * kNB + waves;
-    return d * sizeof(double) + sizeof(int) * (waves + kNB + 2 * kMaxTouched + 4);
+size_t lu_lds_bytes(int nrp) {  // lu_block_kernel
+    size_t d = (size_t)kNB * nrp + 2 * kNB * kNB + kWaves * kNB * kNB + kWaves;
+    return d * sizeof(double) + sizeof(int) * (kWaves + kNB + 2 * kMaxTouched + 4);
 }
 
 }  // namespace
@@ -691,7 +639,7 @@ size_t solve_large_ws_doubles(int nr, int nrhs) {
 
 bool solve_large_supports(int nr) {
     const int nrp = (nr + 15) & ~15;
-    return lu_lds_bytes(nrp) <= 160 * 1024 && rhs_lds_bytes(nrp) <= 160 * 1024 && nrp <= kRhsMaxRows;
+    return (left_looking(nrp) || lu_lds_bytes(nrp) <= 160 * 1024) && rhs_lds_bytes(nrp) <= 160 * 1024 && nrp <= kRhsMaxRows;
 }
 
 // R / Q as in the small kernels (Q != nullptr: R is Gamma and the right-hand side Gamma^T blockdiag(Q)).  `ws` holds
@@ -705,10 +653,6 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
     const size_t per = solve_large_ws_doubles(nr, nrhs);
     const long long chunk = (long long)(ws_doubles / per);
     if (chunk < 1) return MPCX_ERR_UNSUPPORTED;
-    if (lds_bytes > 64 * 1024) {  // only the 512-thread variant gets there
-        hipError_t e = hipFuncSetAttribute((const void *)lu_block_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-    }
     for (long long first = 0; first < batch; first += chunk) {
         const long long count = (batch - first < chunk) ? batch - first : chunk;
         int *failed = (int *)(ws + (size_t)count * nrp * nrp);  // behind the matrices of this launch
@@ -724,10 +668,8 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         if (left_looking(nrp)) {
             const int rc = launch_apply_any<true>(ra, rhs_bytes, s);
             if (rc != 0) return rc;
-        } else if (lu_threads(nrp) == 256) {
-            hipLaunchKernelGGL((lu_block_kernel<256, false>), dim3((unsigned)count), dim3(256), lds_bytes, s, la);
         } else {
-            hipLaunchKernelGGL((lu_block_kernel<512, true>), dim3((unsigned)count), dim3(512), lds_bytes, s, la);
+            hipLaunchKernelGGL(lu_block_kernel, dim3((unsigned)count), dim3(kThreads), lds_bytes, s, la);
         }
         const long long total = count * (long long)((nrhs + kNB - 1) / kNB), per_xcd = (total + 7) / 8;
         if (per_xcd * 8 > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
