@@ -1,8 +1,9 @@
 // Condensed-QP build for plants too large for one lane: ONE WORKGROUP PER INSTANCE, instance-major layout.
 //
-// A, B, C of the instance are staged in LDS.  The Markov blocks G_k = C A^k B and the Phi blocks C A^(k+1) come
-// from two O(f) recurrences that advance together, one barrier per step; every thread owns one output element of
-// a step and keeps its row / column of A or C in registers for the whole loop.  Gamma is then a set of shifted
+// A, B, C of the instance are staged in LDS.  For plants of up to 16 states the Markov blocks G_k = C A^k B, the Phi
+// blocks C A^(k+1) and s_k = Phi_k x0 - ref_k come from power tables built by doubling (about log2 f rounds of 16x16
+// tile products on the matrix cores, one barrier each) and one tile product per 16 output rows (see WgTab); larger
+// plants run the two O(f) recurrences step by step, one barrier per step.  Gamma is then a set of shifted
 // copies of the Markov sequence (kept in LDS as one vector per input column), written column by column with
 // lanes along the rows, so every store instruction covers a contiguous run of a column.  H uses the
 // block-Toeplitz structure of Gamma: with W4 = blockdiag(Q),
@@ -36,34 +37,47 @@ constexpr int kCompute = 256;            // threads that compute and store
 #ifndef MPCX_WG_LOADERS
 #define MPCX_WG_LOADERS 4
 #endif
-#ifndef MPCX_WG_RECUR_ALL
-#define MPCX_WG_RECUR_ALL 1
-#endif
 constexpr int kLoaders = MPCX_WG_LOADERS; // loader waves: each fetches every kLoaders-th column block of W3
 constexpr int kWgBlock = kCompute + 64 * kLoaders;
-constexpr int kRecur = MPCX_WG_RECUR_ALL ? kWgBlock : kCompute;  // threads that take a task of the recurrences
-constexpr int kCoef = 16;                // recurrence coefficients a thread keeps in registers (n <= kCoef)
 
 struct WgLds {
     // offsets in doubles into the dynamic LDS buffer
     int G, S, QG, QS, A, B, C, x0, Q, Wst, Pst, Sr, Z, Pow, Hp, W3r, Tab, total;
 };
 
-// G, S, QG, QS live for the whole kernel.  The inputs, the recurrence states and z are dead once fvec is out, and
-// the H sweep's buffers (two column blocks of H, two of W3) reuse their space.
-// Steps the recurrences advance per iteration (4, 2 or 1): as many as give every task of an iteration its own compute
-// thread and divide f.  with_s: the s = Phi x0 - ref tasks ride along (fvec requested).
-__host__ __device__ inline int wg_stride(int n, int m, int r, int f, bool with_s) {
-    const int per = r * m + r * n + (with_s ? r : 0), nW = n * m;
-    if (f % 4 == 0 && 4 * per + nW <= kRecur) return 4;
-    if (f % 2 == 0 && 2 * per + nW <= kRecur) return 2;
-    return 1;
+// Power tables of the Markov / Phi construction (plants with n <= kTabN states).  With k = Lp hi + lo (Lp a power of
+// two, Lp^2 >= f) every block of the three sequences is one short product of two table entries:
+//     Phi block k = (C A^lo) (A^(Lp hi + 1)),   G_k = (C A^lo) (A^(Lp hi) B),   s_k = (C A^lo) (A^(Lp hi + 1) x0) - ref_k,
+// so the serial chain of f steps becomes log2(Lp) + log2(nh) doubling rounds that build the tables (nh = ceil(f / Lp)
+// values of hi), and all blocks then come from independent 16x16 products on the matrix cores.
+struct WgTab {
+    int Lp, nh, RP;          // lo range, hi range, rows of the (C A^lo) table padded to whole tiles of 16
+    int PP, TC, X, Y, total; // offsets (doubles) from the tables' base: ping-pong powers, C A^lo, A^(Lp hi + 1), [A^(Lp hi) B | A^(Lp hi + 1) x0]
+};
+constexpr int kTabN = 16;
+__host__ __device__ inline WgTab wg_tab_layout(int n, int m, int r, int f) {
+    WgTab T;
+    int Lp = 1;
+    while (Lp * Lp < f) Lp *= 2;
+    T.Lp = Lp;
+    T.nh = (f + Lp - 1) / Lp;
+    T.RP = (Lp * r + 15) & ~15;
+    int o = 0;
+    T.PP = o; o += 2 * n * n;
+    T.TC = o; o += n * T.RP;
+    T.X = o; o += T.nh * n * n;
+    T.Y = o; o += T.nh * n * (m + 1);
+    T.total = o;
+    return T;
 }
 
+// G, S, QG, QS live for the whole kernel.  The inputs, the recurrence states and z are dead once fvec is out, and
+// the H sweep's buffers (two column blocks of H, two of W3) reuse their space.
 __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v) {
     WgLds L;
     int o = 0;
     const int fr = f * r, nl = f - v + 1;
+    const bool tables = n <= kTabN;
     L.G = o; o += m * fr;        // [c][k*r + a] = G_k[a][c]
     L.S = o; o += m * nl * r;    // [c][j*r + a] = S_j[a][c]
     L.QG = o; o += m * fr;       // Q G_k, same indexing as G
@@ -74,14 +88,13 @@ __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v
     L.C = o; o += r * n;
     L.x0 = o; o += 2 * n;      // x0, then A x0
     L.Q = o; o += r * r;
-    L.Wst = o; o += 2 * n * m;   // Markov state, ping-pong
-    L.Pst = o; o += 2 * r * n;   // Phi state, ping-pong
+    L.Wst = o; o += tables ? 0 : 2 * n * m;   // Markov state, ping-pong (plants beyond kTabN states)
+    L.Pst = o; o += tables ? 0 : 2 * r * n;   // Phi state, ping-pong
     L.Sr = o; o += fr;           // ref, then Phi x0 - ref
     L.Z = o; o += fr;            // Q (Phi x0 - ref)
-    // strided recurrences only (the stride without the s tasks is the larger of the two): A^2..A^4, C A..C A^3, A x0..A^4 x0.
-    // They are dead when the recurrences end, before Q G is formed: they borrow its space when it is large enough.
-    const int pow_sz = wg_stride(n, m, r, f, false) > 1 ? 3 * n * n + 3 * r * n + 4 * n : 0;
-    if (pow_sz <= m * fr) { L.Pow = L.QG; } else { L.Pow = o; o += pow_sz; }
+    // The power tables are dead before S, Q G and Q S are formed: they borrow that space when it is large enough.
+    const int tab_sz = tables ? wg_tab_layout(n, m, r, f).total : 0;
+    if (tab_sz <= u - L.S) { L.Pow = L.S; } else { L.Pow = o; o += tab_sz; }
     const int end1 = o;
     o = u;
     L.Hp = o; o += 2 * (v + 1) * m * m;  // column block of the swept Gram matrix, ping-pong: [slot][i*m + j][a], a = 0..v
@@ -436,8 +449,9 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
 
     // ---- every per-instance input goes to LDS before the first store of the workgroup ----
     for (int e = tid; e < n * n; e += kWgBlock) sA[e] = gA[e];
-    for (int e = tid; e < n * m; e += kWgBlock) { const double x = gB[e]; sB[e] = x; sW[e] = x; }
-    for (int e = tid; e < r * n; e += kWgBlock) { const double x = gC[e]; sC[e] = x; sP[e] = x; }
+    const bool tables = n <= kTabN;  // wave-uniform: power tables instead of the step-by-step recurrences
+    for (int e = tid; e < n * m; e += kWgBlock) { const double x = gB[e]; sB[e] = x; if (!tables) sW[e] = x; }
+    for (int e = tid; e < r * n; e += kWgBlock) { const double x = gC[e]; sC[e] = x; if (!tables) sP[e] = x; }
     if (p.fvec) {
         for (int e = tid; e < n; e += kWgBlock) sx0[e] = p.x0[b * n + e];
         for (int e = tid; e < FR; e += kWgBlock) sSr[e] = p.ref[b * (long long)FR + e];
@@ -459,117 +473,110 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         }
         lds_barrier();
     }
-    const bool one_task = (nT <= kRecur) && (n <= kCoef);
-    if (one_task) {
-        // Stride: the recurrences are a serial chain of f steps, one LDS round trip and one barrier each.  Where the
-        // threads allow it a step advances the states by A^st (st = 4 or 2) and produces the st Markov blocks, Phi
-        // blocks and s vectors in between from the same state: G_(k+j) = (C A^j) W_k, Phi block k+j = P_k A^(j+1),
-        // s_(k+j) = P_k (A^(j+1) x0) - ref_(k+j).  Still one dot product per thread and step, f / st steps.
-        const int st = wg_stride(n, m, r, f, nS > 0);
-        double *sPow = lds + L.Pow, *sCA = sPow + 3 * n * n, *sAjx = sCA + 3 * r * n;
-        auto Apow = [&](int j) -> const double * { return j == 1 ? sA : sPow + (j - 2) * n * n; };   // A^j, j = 1..4
-        auto CApow = [&](int j) -> const double * { return j == 0 ? sC : sCA + (j - 1) * r * n; };  // C A^j, j = 0..3
-        auto Ajx = [&](int j) -> const double * { return j == 1 ? sAx : sAjx + (j - 1) * n; };      // A^j x0, j = 1..4
-        if (st > 1) {
-            auto matmul = [&](double *dst, const double *X, const double *Y, int rows) {  // dst (rows x n) = X (rows x n) Y (n x n)
-                for (int e = tid; e < rows * n; e += kWgBlock) {
-                    const int i = e % rows, j2 = e / rows;
-                    double acc = 0.0;
-                    for (int q = 0; q < n; ++q) acc += X[q * rows + i] * Y[j2 * n + q];
-                    dst[e] = acc;
-                }
-            };
-            matmul(sPow, sA, sA, n);
-            lds_barrier();
-            if (st > 2) {
-                matmul(sPow + n * n, sPow, sA, n);
-                matmul(sPow + 2 * n * n, sPow, sPow, n);
-                lds_barrier();
-            }
-            for (int j = 1; j < st; ++j) matmul(sCA + (j - 1) * r * n, sC, Apow(j), r);
-            if (p.fvec) {
-                for (int e = tid; e < (st - 1) * n; e += kWgBlock) {  // A^j x0 = A^j times x0, j = 2..st
-                    const int j = 2 + e / n, i = e % n;
-                    const double *X = Apow(j);
-                    double acc = 0.0;
-                    for (int q = 0; q < n; ++q) acc += X[q * n + i] * sx0[q];
-                    sAjx[(j - 1) * n + i] = acc;
-                }
-            }
-            lds_barrier();
+    if (tables) {
+        // ---- power tables by doubling, then every block from one product on the matrix cores ----
+        const WgTab T = wg_tab_layout(n, m, r, f);
+        double *tb = lds + L.Pow;
+        double *sPP = tb + T.PP, *sTC = tb + T.TC, *sX = tb + T.X, *sY = tb + T.Y;
+        const int Lp = T.Lp, nh = T.nh, RP = T.RP, nn = n * n, m1 = m + 1;
+        // sTC[q * RP + rho] = (C A^lo)[a][q], rho = lo r + a;  sX[h] = A^(Lp h + 1) (n x n, column-major);
+        // sY[h] = [A^(Lp h) B | A^(Lp h + 1) x0] (n x (m + 1), column-major; the last column only with fvec)
+        for (int e = tid; e < n * RP; e += kWgBlock) {
+            const int q = e / RP, rho = e - q * RP;
+            sTC[e] = (rho < r) ? sC[q * r + rho] : 0.0;
         }
-        // decode this thread's task once; its coefficients stay in registers for all steps
-        const int tG = st * nG, tP = st * nP, tS = st * nS, nTs = tG + nW + tP + tS;
-        int kind = -1, op_off = 0, op_stride = 1, out_off = 0;
-        bool wr_state = true;
-        long long phi_off = 0;
-        double coef[kCoef];
+        for (int e = tid; e < nn; e += kWgBlock) { const double x = sA[e]; sPP[e] = x; sX[e] = x; }
+        for (int e = tid; e < n * m1; e += kWgBlock) sY[e] = (e < n * m) ? sB[e] : (p.fvec ? sAx[e - n * m] : 0.0);
+        lds_barrier();
+        // All products of the rounds and of the block phase are 16-row tiles on the matrix cores, transposed so that
+        // lanes run along the rows (conflict-free LDS accesses, contiguous global stores):
+        //   D[j2][row] = sum_q Yt[j2][q] . X[row0 + row][q],  Yt[j2][q] = Y[j2 * n + q] (n x ncol, column-major),
+        //   X[row][q] = X[q * ldx + row].  A wavefront takes one tile; operand reads all issue before the first product.
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+        const int KS = (n + 3) / 4;
+        auto tile = [&](const double *X, int ldx, int row0, int nrow, const double *Y, int ncol) -> d4 {
+            double av[kTabN / 4], bv[kTabN / 4];
 #pragma unroll
-        for (int j = 0; j < kCoef; ++j) coef[j] = 0.0;
-        if (tid < kRecur && tid < nTs) {
-            if (tid < tG) {
-                const int jj = tid / nG, u = tid - jj * nG, a = u % r, c = u / r;
-                const double *X = CApow(jj);
-                kind = 0; op_off = c * n; op_stride = 1; out_off = c * FR + jj * r + a;
-#pragma unroll
-                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = X[j * r + a];
-            } else if (tid < tG + nW) {
-                const int u = tid - tG, i = u % n, c = u / n;
-                const double *X = Apow(st);
-                kind = 1; op_off = c * n; op_stride = 1; out_off = u;
-#pragma unroll
-                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = X[j * n + i];
-            } else if (tid < tG + nW + tP) {
-                const int t2 = tid - tG - nW, jj = t2 / nP, u = t2 - jj * nP, a = u % r, j2 = u / r;
-                const double *X = Apow(jj + 1);
-                kind = 2; op_off = a; op_stride = r; out_off = u; phi_off = (long long)j2 * FR + jj * r + a;
-                wr_state = (jj == st - 1);
-#pragma unroll
-                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = X[j2 * n + j];
-            } else {
-                const int t2 = tid - tG - nW - tP, jj = t2 / r, a = t2 - jj * r;
-                const double *X = Ajx(jj + 1);
-                kind = 3; op_off = a; op_stride = r; out_off = jj * r + a;
-#pragma unroll
-                for (int j = 0; j < kCoef; ++j) if (j < n) coef[j] = X[j];
+            for (int ks = 0; ks < kTabN / 4; ++ks) {
+                const int q = 4 * ks + kq, qq = q < n ? q : 0;
+                const double a0 = Y[(l15 < ncol ? l15 : 0) * n + qq];
+                const double b0 = X[qq * ldx + row0 + (l15 < nrow ? l15 : 0)];
+                av[ks] = (q < n && l15 < ncol) ? a0 : 0.0;
+                bv[ks] = (q < n && l15 < nrow) ? b0 : 0.0;
             }
-        }
-        // The dot product is as long as the smallest of 8, 12, 16 that holds n (shorter serial chain, fewer LDS reads),
-        // and runs as two partial sums.
-        auto recur = [&](auto width) {
-            constexpr int KC = decltype(width)::value;
-            for (int k = 0, it = 0; k < f; k += st, ++it) {
-                const double *Wc = sW + (it & 1) * nW;
-                double *Wn = sW + ((it + 1) & 1) * nW;
-                const double *Pc = sP + (it & 1) * nP;
-                double *Pn = sP + ((it + 1) & 1) * nP;
-                if (kind >= 0) {
-                    const double *op = (kind >= 2 ? Pc : Wc) + op_off;
-                    double s0 = 0.0, s1 = 0.0;
-                    // unconditional loads (index clamped, coefficient zero past n): all issue together, one wait
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int j = 0; j < KC; j += 2) {
-                        s0 += coef[j] * op[(j < n ? j : n - 1) * op_stride];
-                        s1 += coef[j + 1] * op[(j + 1 < n ? j + 1 : n - 1) * op_stride];
-                    }
-                    const double s = s0 + s1;
-                    if (kind == 0) {
-                        sG[out_off + k * r] = s;
-                    } else if (kind == 1) {
-                        Wn[out_off] = s;
-                    } else if (kind == 2) {
-                        if (wr_state) Pn[out_off] = s;
-                        if (gPhi) gPhi[phi_off + k * r] = s;
-                    } else {
-                        sSr[k * r + out_off] = s - sSr[k * r + out_off];
-                    }
-                }
-                lds_barrier();
-            }
+            for (int ks = 0; ks < kTabN / 4; ++ks)
+                if (ks < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+            return acc;  // acc[reg] = D[j2 = kq + 4 reg][row = l15]
         };
-        if (n <= 8) recur(std::integral_constant<int, 8>{});
-        else if (n <= 12) recur(std::integral_constant<int, 12>{});
-        else recur(std::integral_constant<int, kCoef>{});
+        auto put = [&](double *dst, int ldd, int row0, int nrow, int ncol, d4 acc) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (kq + 4 * reg < ncol && l15 < nrow) dst[(kq + 4 * reg) * ldd + row0 + l15] = acc[reg];
+        };
+        constexpr int NWV = kWgBlock / 64;
+        int cur = 0;
+        for (int g = 1; g < Lp; g *= 2) {  // rows [g r, 2 g r) of the C A^lo table from rows [0, g r); A^g squared
+            const double *Ap = sPP + cur * nn;
+            const int tiles_tc = (g * r + 15) / 16;
+            for (int t = wave; t < 1 + tiles_tc; t += NWV) {
+                if (t == 0) {
+                    put(sPP + (cur ^ 1) * nn, n, 0, n, n, tile(Ap, n, 0, n, Ap, n));
+                } else {
+                    const int row0 = (t - 1) * 16, nrow = (g * r - row0 < 16) ? g * r - row0 : 16;
+                    put(sTC + g * r, RP, row0, nrow, n, tile(sTC, RP, row0, nrow, Ap, n));
+                }
+            }
+            cur ^= 1;
+            lds_barrier();
+        }
+        for (int g = 1; g < nh; g *= 2) {  // entries [g, 2 g) of the hi tables from entries [0, g); (A^Lp)^g squared
+            const double *Mp = sPP + cur * nn;
+            const int cnt = (2 * g <= nh ? g : nh - g), sq = (2 * g < nh) ? 1 : 0;
+            for (int t = wave; t < sq + 2 * cnt; t += NWV) {
+                if (t < sq) {
+                    put(sPP + (cur ^ 1) * nn, n, 0, n, n, tile(Mp, n, 0, n, Mp, n));
+                } else {
+                    const int u = t - sq, hh = u >> 1;
+                    if (u & 1) put(sY + (g + hh) * n * m1, n, 0, n, m1, tile(Mp, n, 0, n, sY + hh * n * m1, m1));
+                    else put(sX + (g + hh) * nn, n, 0, n, n, tile(Mp, n, 0, n, sX + hh * nn, n));
+                }
+            }
+            cur ^= 1;
+            lds_barrier();
+        }
+        // Blocks: D[c][rho] = sum_q R_h[q][c] . (C A^lo)[rho][q],  R_h = A^(Lp h + 1) (Phi) or sY[h] (G and s)
+        {
+            const int RT = (Lp * r + 15) / 16;
+            const int cols_gs = m + (p.fvec ? 1 : 0), CT = (cols_gs + 15) / 16;  // column tiles of the G / s product
+            const int kinds = (gPhi ? 1 : 0) + CT;                                // Phi has one column tile (n <= 16)
+            int cntr = 0;
+            for (int h = 0; h < nh; ++h)
+            for (int rt = 0; rt < RT; ++rt)
+            for (int kind = 0; kind < kinds; ++kind) {
+                if ((cntr++ % NWV) != wave) continue;
+                const bool is_phi = gPhi && kind == 0;
+                const int ct = is_phi ? 0 : kind - (gPhi ? 1 : 0);
+                const double *R = (is_phi ? sX + h * nn : sY + h * n * m1) + ct * 16 * n;
+                const int ncol = (is_phi ? n : cols_gs) - ct * 16;
+                const d4 acc = tile(sTC, RP, rt * 16, 16, R, ncol < 16 ? ncol : 16);
+                const int rho = rt * 16 + l15, row = Lp * h * r + rho;
+                if (rho < Lp * r && row < FR) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int c = ct * 16 + kq + 4 * reg;
+                        if (is_phi) {
+                            if (c < n) gPhi[(long long)c * FR + row] = acc[reg];
+                        } else if (c < m) {
+                            sG[c * FR + row] = acc[reg];
+                        } else if (c == m && p.fvec) {
+                            sSr[row] = acc[reg] - sSr[row];
+                        }
+                    }
+                }
+            }
+        }
     } else {
         for (int k = 0; k < f; ++k) {
             const double *Wc = sW + (k & 1) * nW;
