@@ -18,6 +18,8 @@ cases=(
  "rollout_msd|--workload msd --op rollout --steps 5 --warmup 1"
  "rollout_two_mass|--workload two_mass --op rollout --steps 5 --warmup 1"
  "rollout_quadrotor|--workload quadrotor --op rollout --steps 5 --warmup 1"
+ "gain_long|--workload long --op gain --steps 2 --warmup 1"
+ "gain_quadrotor|--workload quadrotor --op gain --steps 2 --warmup 1"
 )
 for c in "${cases[@]}"; do
   name=${c%%|*}; args=${c#*|}
@@ -27,7 +29,7 @@ for c in "${cases[@]}"; do
   fi
   if [ "$what" != "kt" ]; then
     for ctr in WRITE_SIZE FETCH_SIZE; do
-      timeout -s KILL 200 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_${name}_$ctr -o out -- python3 $R/bench.py $B --steps 2 --warmup 1 ${args/--steps 5 --warmup 1/} > $O/pmc_${name}_$ctr.json 2> $O/pmc_${name}_$ctr.err
+      timeout -s KILL 200 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_${name}_$ctr -o out -- python3 $R/bench.py $B --steps 2 --warmup 1 $(echo $args | sed -e 's/--steps [0-9]* --warmup [0-9]*//') > $O/pmc_${name}_$ctr.json 2> $O/pmc_${name}_$ctr.err
     done
     echo "pmc $name done"
   fi
