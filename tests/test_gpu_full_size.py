@@ -328,3 +328,67 @@ def test_gain_solve_loop_full_size(ctx, torch_dev, name):
         note("y = C x", _rel(Yv[sl], Cm[sl] @ xs[:, :, :T]))
     bad = {k: e for k, e in worst.items() if not e <= RTOL}
     assert not bad, f"{name} (batch {batch}): {bad}"
+
+
+@pytest.mark.parametrize("name", ["quadrotor", "long"])
+def test_blocked_gain_solve_full_size(ctx, torch_dev, name):
+    """Build -> gain / solve through the blocked solver (200 and 800 unknowns) at the full batch
+    (controller.rs:93-96, :130-134): every instance is held to the backward-error bound
+    ||H X - R|| <= 1e-10 (||H|| ||X|| + ||R||), which does not depend on cond(H), and a few instances to the CPU oracle."""
+    torch, dev = torch_dev
+    from mpc_rs_amd import ffi, layout as L, synth
+    from oracle import oracle_ffi as orc
+
+    batch = FULL[name]
+    d = synth.make_batch(name, batch)
+    n, m, r, f, v = d["n"], d["m"], d["r"], d["f"], d["v"]
+    FR, VM = f * r, v * m
+    il = 1
+    bufs = _resident(torch, dev, d, il, batch)
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def out(elems):
+        return torch.full((L.array_elems(batch, il, elems),), float("nan"), dtype=torch.float64, device=dev)
+    qp = {"Gamma": out(FR * VM), "H": out(VM * VM), "fvec": out(VM)}
+    dims = ffi.make_dims(n, m, r, f, v, batch, 0, il)
+    ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["W3"].data_ptr(),
+                     bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(), None,
+                     qp["Gamma"].data_ptr(), qp["H"].data_ptr(), qp["fvec"].data_ptr(), sp)
+    info_g = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    info_s = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+    gain, useq = out(VM * FR), out(VM)
+    ctx.qp_gain_dev(dims, qp["H"].data_ptr(), qp["Gamma"].data_ptr(), bufs["Q"].data_ptr(), gain.data_ptr(),
+                    info_g.data_ptr(), sp)
+    ctx.qp_solve_dev(dims, qp["H"].data_ptr(), qp["fvec"].data_ptr(), useq.data_ptr(), info_s.data_ptr(), sp)
+    torch.cuda.synchronize()
+    assert int((info_g != 0).sum()) == 0 and int((info_s != 0).sum()) == 0, "an instance was flagged singular"
+
+    Q = bufs["Q"].view(r, r).t()
+    Gam, H, fv = (_view(qp[k], batch, *s, il) for k, s in
+                  {"Gamma": (FR, VM), "H": (VM, VM), "fvec": (VM, 1)}.items())
+    K, us = _view(gain, batch, VM, FR, il), _view(useq, batch, VM, 1, il)
+    fro = lambda a: torch.linalg.vector_norm(a.reshape(a.shape[0], -1), dim=1)
+    worst = {"H gain = Gamma^T W4": 0.0, "H u = -fvec": 0.0}
+    step = CHUNK[name]
+    for lo in range(0, batch, step):
+        sl = slice(lo, min(lo + step, batch))
+        h, g, k_, u_ = H[sl].contiguous(), Gam[sl].contiguous(), K[sl].contiguous(), us[sl].contiguous()
+        b = h.shape[0]
+        rhs = torch.einsum("bfqc,qp->bcfp", g.view(b, f, r, VM), Q).reshape(b, VM, FR)   # Gamma^T blockdiag(Q)
+        worst["H gain = Gamma^T W4"] = max(worst["H gain = Gamma^T W4"],
+                                           float(((fro(h @ k_ - rhs)) / (fro(h) * fro(k_) + fro(rhs))).max()))
+        worst["H u = -fvec"] = max(worst["H u = -fvec"],
+                                   float(((fro(h @ u_ + fv[sl])) / (fro(h) * fro(u_) + fro(fv[sl]))).max()))
+    bad = {k: e for k, e in worst.items() if not e <= RTOL}
+    assert not bad, f"{name} (batch {batch}): {bad}"
+
+    # a few instances against the oracle's gain, scaled by the conditioning of their Hessian
+    for i in _sample_indices(batch, il, 3, 11):
+        Hi = np.ascontiguousarray(H[i].cpu().numpy())
+        ok, inv = orc.try_inverse(Hi)
+        assert ok
+        want = inv @ (Gam[i].cpu().numpy().T @ np.kron(np.eye(f), d["Q"]))                 # controller.rs:93-96
+        got = K[i].cpu().numpy()
+        cond = np.linalg.cond(Hi)
+        err = np.linalg.norm(got - want) / np.linalg.norm(want)
+        assert err <= 1e-11 * cond, f"{name} instance {i}: gain differs from the oracle by {err:.2e} (cond {cond:.1e})"
