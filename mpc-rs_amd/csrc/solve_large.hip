@@ -29,6 +29,9 @@
 // formed from the caller's arrays as it is loaded (Gamma^T blockdiag(Q) included), so a right-hand side is read once
 // and its solution written once, and never enters the workspace; the workgroups of one instance run on one XCD and
 // read the same multipliers at about the same time (L2 hits).
+#include <type_traits>
+#include <utility>
+
 #include "mpcx_internal.h"
 
 namespace mpcx {
@@ -36,7 +39,19 @@ namespace {
 
 using d4 = __attribute__((ext_vector_type(4))) double;
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant in every pass
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 constexpr int kNB = 16;
+constexpr int kSmallRows = 256;           // up to here H is factored right-looking by lu_block_kernel, beyond left-looking
+constexpr int kRhsMaxRows = 8 * 10 * kNB; // the widest variant of lu_apply_kernel: 8 wavefronts x 10 row tiles
 constexpr int kMaxTouched = 2 * kNB;
 
 struct LuArgs {
@@ -70,6 +85,178 @@ __global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p) {
 }
 
 // ---- factor / eliminate: one workgroup per instance ----
+// Panel factorisation of the column block in LDS (blk[c * ld + row], 16 columns x nrp rows, pivot block at row k0) and
+// what it leaves behind: the block itself back in the workspace (gcol), L11^-1, U11^-1 and the exchange lists in the
+// panel's description (mt).  RPT: rows a thread holds (RPT THREADS >= nrp).  Returns false on a zero or non-finite
+// pivot.  Kept out of line: inlined into
+// lu_apply_kernel its registers pushed the multipliers of the panel sweep into scratch memory, whose reloads then
+// waited behind the prefetched loads of the next panel.
+template <int THREADS, int RPT>
+__device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, double *linv, double *uinv, int *tmeta,
+                                          double *red_val, int *red_idx, int *ipiv, double *gcol, double *mt) {
+    constexpr int NW = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int *tcount = tmeta, *trow = tmeta + 1, *tsrc = tmeta + 1 + kMaxTouched;
+    // The panel column by column: pivot searched among the rows at positions >= k0 + jc, every row outside the pivot
+    // block reduced.  A thread keeps its rows (RPT of them, 16 entries each) in registers for all 16 columns; a row
+    // never moves, its POSITION does (an exchange swaps two positions), and the rows go back to LDS at their final
+    // positions.  Per column only the pivot row travels (its owner publishes it, everybody reads it back as a
+    // broadcast): two barriers and about 20 LDS instructions per wavefront instead of three barriers and a
+    // read-modify-write of every entry.
+    double a[RPT][kNB];
+    int pos[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int rr = tid + u * THREADS;
+        pos[u] = rr < nrp ? rr : -1;  // -1: no row
+#pragma unroll
+        for (int c = 0; c < kNB; ++c) a[u][c] = blk[c * ld + (rr < nrp ? rr : 0)];
+    }
+    double *pbuf = linv;  // the pivot row of the current column (L11^-1 is formed after the last column)
+    bool failed = false;  // uniform over the workgroup
+    static_for<kNB>([&](auto JC) __attribute__((always_inline)) {
+        constexpr int jc = decltype(JC)::value;  // a constant in every pass: the rows stay in registers
+        if (failed) return;
+        const int kk = k0 + jc;
+        double best = -1.0;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (pos[u] >= kk) {
+                double x = fabs(a[u][jc]);
+                if (!(x == x)) x = INFINITY;  // a NaN must be chosen (and fail), not skipped
+                if (x > best || (x == best && pos[u] < bi)) { best = x; bi = pos[u]; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { red_val[wv] = best; red_idx[wv] = bi; }
+        __syncthreads();
+        best = red_val[0];
+        bi = red_idx[0];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) {
+            const double ob = red_val[w2];
+            const int oi = red_idx[w2];
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (!(best > 0.0) || !isfinite(best)) { failed = true; return; }
+        if (tid == 0) ipiv[jc] = bi;
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (pos[u] == bi) {  // the pivot row: published, and moved to position kk
+#pragma unroll
+                for (int c = jc; c < kNB; ++c) pbuf[c] = a[u][c];
+                pos[u] = kk;
+            } else if (pos[u] == kk) {
+                pos[u] = bi;
+            }
+        }
+        __syncthreads();
+        double pv[kNB];
+#pragma unroll
+        for (int c = jc; c < kNB; ++c) pv[c] = pbuf[c];
+        const double inv = 1.0 / pv[jc];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            if (pos[u] < 0 || (pos[u] >= k0 && pos[u] <= kk)) continue;  // the panel's pivot rows keep their entry: it belongs to U11
+            const double l = a[u][jc] * inv;
+            a[u][jc] = l;
+#pragma unroll
+            for (int c = jc + 1; c < kNB; ++c) a[u][c] -= l * pv[c];
+        }
+    });
+    if (failed) return false;
+    __syncthreads();  // (the last column's readers of pbuf are done: it becomes L11^-1 below)
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        if (pos[u] >= 0) {
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) blk[c * ld + pos[u]] = a[u][c];
+        }
+    }
+    __syncthreads();
+    // What the later blocks and the right-hand sides need of this panel, three wavefronts side by side:
+    if (tid < kNB) {  // column tid of L11^-1 by forward substitution on a unit vector (every read of the panel issued first)
+        double x[kNB];
+#pragma unroll
+        for (int i = 0; i < kNB; ++i) {
+            double sacc = (i == tid) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < kNB; ++q)
+                if (q < i) sacc -= blk[q * ld + k0 + i] * x[q];
+            x[i] = sacc;
+            linv[i * kNB + tid] = sacc;
+        }
+    }
+    if (tid >= 128 && tid < 128 + kNB) {  // column of U11^-1 by backward substitution
+        const int jc = tid - 128;
+        double x[kNB];
+#pragma unroll
+        for (int i = kNB - 1; i >= 0; --i) {
+            double sacc = (i == jc) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = kNB - 1; q >= 0; --q)
+                if (q > i) sacc -= blk[q * ld + k0 + i] * x[q];
+            x[i] = sacc / blk[i * ld + k0 + i];
+            uinv[i * kNB + jc] = x[i];
+        }
+    }
+    if (wv == 1) {
+        // Net effect of the 16 exchanges: which rows end up with whose old content.  Lane q < 16 stands for row k0 + q,
+        // lanes from 16 on for the rows outside the pivot block in the order the exchanges first meet them; a lane
+        // carries the row whose old content its row receives.  One exchange is two lane-to-lane moves, no memory.
+        const int myp = ipiv[lane & 15];
+        int row = k0 + lane, src = k0 + lane, nt = kNB;
+        for (int jc = 0; jc < kNB; ++jc) {
+            const int bq = __shfl(myp, jc);  // uniform
+            if (bq == k0 + jc) continue;
+            int ib;
+            if (bq < k0 + kNB) {
+                ib = bq - k0;  // (a pivot is never searched above its own column, so bq >= k0 + jc)
+            } else {
+                const unsigned long long hit = __ballot(lane >= kNB && lane < nt && row == bq);
+                if (hit) {
+                    ib = __ffsll((long long)hit) - 1;
+                } else {
+                    ib = nt++;
+                    if (lane == ib) { row = bq; src = bq; }
+                }
+            }
+            const int sj = __shfl(src, jc), sb = __shfl(src, ib);
+            if (lane == jc) src = sb;
+            if (lane == ib) src = sj;
+        }
+        if (lane < kMaxTouched) { trow[lane] = row; tsrc[lane] = src; }
+        if (lane == 0) *tcount = nt;
+    }
+    __syncthreads();
+    // the block goes back to the workspace (one contiguous run), 16-byte pieces, every LDS read of a round issued first
+    {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const int pairs = kNB * nrp / 2;  // nrp is a multiple of 16: a pair never straddles two columns
+        for (int e0 = tid; e0 < pairs; e0 += 8 * THREADS) {
+            v2d v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * THREADS, ee = e < pairs ? e : 0, c = (2 * ee) / nrp, row2 = 2 * ee - c * nrp;
+                v[u] = *(const v2d *)(blk + c * ld + row2);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * THREADS;
+                if (e < pairs) *(v2d *)(gcol + 2 * e) = v[u];
+            }
+        }
+    }
+    if (tid < kNB * kNB) { mt[tid] = linv[tid]; mt[kNB * kNB + tid] = uinv[tid]; }
+    if (tid < 1 + 2 * kMaxTouched) ((int *)(mt + kMetaInts))[tid] = tmeta[tid];
+    return true;
+}
+
 // Right-looking, for systems of up to kSmallRows rows: their time goes into the barriers of the panel factorization, and
 // a workgroup of 256 threads within 128 registers lets four instances share a CU.  (Larger systems are factored
 // left-looking by lu_apply_kernel<..., true>, which moves half the bytes.)
@@ -85,9 +272,10 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
     double *red_val = tiles + kWaves * kNB * kNB;        // [kWaves]
     int *red_idx = (int *)(red_val + kWaves);            // [kWaves]
     int *ipiv = red_idx + kWaves;                        // [16]
-    int *trow = ipiv + kNB;                              // [32] rows whose content changes with the panel's exchanges
+    int *tmeta = ipiv + kNB;                             // tcount, trow[32], tsrc[32] (as in a panel's description)
+    int *tcount = tmeta;
+    int *trow = tmeta + 1;                               // [32] rows whose content changes with the panel's exchanges
     int *tsrc = trow + kMaxTouched;                      // [32] the row whose old content each of them receives
-    int *tcount = tsrc + kMaxTouched;                    // [1]
     double *A = p.ws + (size_t)blockIdx.x * nrp * nrp;
     double *mytile = tiles + wv * kNB * kNB;
 
@@ -98,104 +286,13 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
             for (int e = tid; e < kNB * nrp; e += kThreads) panel[e] = src[e];
         }
         __syncthreads();
-        for (int j = 0; j < kNB; ++j) {
-            double *col = panel + (size_t)j * nrp;
-            const int kk = k0 + j;
-            double best = -1.0;
-            int bi = kk;
-            for (int r = kk + tid; r < nrp; r += kThreads) {
-                double a = fabs(col[r]);
-                if (!(a == a)) a = INFINITY;  // a NaN must be chosen (and fail), not skipped
-                if (a > best) { best = a; bi = r; }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int oi = __shfl_xor(bi, off);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (lane == 0) { red_val[wv] = best; red_idx[wv] = bi; }
-            __syncthreads();
-            best = red_val[0];
-            bi = red_idx[0];
-#pragma unroll
-            for (int w = 1; w < kWaves; ++w) {
-                const double ob = red_val[w];
-                const int oi = red_idx[w];
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (!(best > 0.0) || !isfinite(best)) {  // uniform over the workgroup
-                if (tid == 0) p.failed[blockIdx.x] = 1;
-                return;
-            }
-            if (tid < kNB) {
-                const double t = panel[(size_t)tid * nrp + kk];
-                panel[(size_t)tid * nrp + kk] = panel[(size_t)tid * nrp + bi];
-                panel[(size_t)tid * nrp + bi] = t;
-                if (tid == 0) ipiv[j] = bi;
-            }
-            __syncthreads();
-            const double inv = 1.0 / col[kk];
-            for (int r = tid; r < nrp; r += kThreads) {
-                if (r >= k0 && r <= kk) continue;  // the panel's earlier pivot rows keep their entry: it belongs to U11
-                const double l = col[r] * inv;
-                col[r] = l;
-#pragma unroll
-                for (int jj = 1; jj < kNB; ++jj)
-                    if (j + jj < kNB) panel[(size_t)(j + jj) * nrp + r] -= l * panel[(size_t)(j + jj) * nrp + kk];
-            }
-            __syncthreads();
-        }
-        // 2. panel back to the workspace (U11 is needed by the final solve), inverse of the unit lower triangle, and the
-        //    net effect of the 16 exchanges: which rows end up with whose old content
-        {
-            double *dst = A + (size_t)k0 * nrp;
-            for (int e = tid; e < kNB * nrp; e += kThreads) dst[e] = panel[e];
-        }
-        if (tid < kNB) {  // column tid of L11^-1 by forward substitution on a unit vector
-            double x[kNB];
-#pragma unroll
-            for (int i = 0; i < kNB; ++i) {
-                double s = (i == tid) ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 0; q < kNB; ++q)
-                    if (q < i) s -= panel[(size_t)q * nrp + k0 + i] * x[q];
-                x[i] = s;
-                linv[i * kNB + tid] = s;
-            }
-        }
-        if (tid >= 128 && tid < 128 + kNB) {  // column j of U11^-1 by backward substitution on a unit vector (a third wavefront)
-            const int j = tid - 128;  // the column is kept in LDS as it grows: a lane reads back only what it wrote
-#pragma unroll 1
-            for (int i = kNB - 1; i >= 0; --i) {
-                double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll 5
-                for (int q = kNB - 1; q > i; --q) s -= panel[(size_t)q * nrp + k0 + i] * uinv[q * kNB + j];
-                uinv[i * kNB + j] = s / panel[(size_t)i * nrp + k0 + i];
-            }
-        }
-        if (tid == 64) {  // another wavefront than the one inverting L11
-            int n = kNB;
-            for (int q = 0; q < kNB; ++q) { trow[q] = k0 + q; tsrc[q] = k0 + q; }
-            for (int j = 0; j < kNB; ++j) {
-                const int b = ipiv[j];
-                if (b == k0 + j) continue;
-                int ib = -1;
-                for (int q = 0; q < n; ++q)
-                    if (trow[q] == b) ib = q;
-                if (ib < 0) { ib = n; trow[n] = b; tsrc[n] = b; ++n; }
-                const int t = tsrc[j];
-                tsrc[j] = tsrc[ib];
-                tsrc[ib] = t;
-            }
-            *tcount = n;
-        }
-        __syncthreads();
-        if (p.meta) {  // what the right-hand sides need to follow this panel
-            double *mt = p.meta + ((size_t)blockIdx.x * (nrp / kNB) + k0 / kNB) * kMetaDoubles;
-            if (tid < kNB * kNB) { mt[tid] = linv[tid]; mt[kNB * kNB + tid] = uinv[tid]; }
-            int *mi = (int *)(mt + kMetaInts);
-            if (tid == 0) mi[0] = *tcount;
-            if (tid < kMaxTouched) { mi[1 + tid] = trow[tid]; mi[1 + kMaxTouched + tid] = tsrc[tid]; }
+        // 2. factored in LDS; the panel goes back to the workspace (U11 is needed at the end) together with L11^-1,
+        //    U11^-1 and the net effect of the 16 exchanges (which rows end up with whose old content)
+        if (!factor_block<kThreads, kSmallRows / kThreads>(panel, nrp, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv,
+                                                           A + (size_t)k0 * nrp,
+                                                           p.meta + ((size_t)blockIdx.x * (nrp / kNB) + k0 / kNB) * kMetaDoubles)) {
+            if (tid == 0) p.failed[blockIdx.x] = 1;  // uniform over the workgroup
+            return;
         }
         // 3. the columns to the right, one block of 16 per wavefront at a time
         const int ntouched = *tcount;
@@ -448,114 +545,54 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
         int *red_idx = (int *)(red_val + NW);                       // [NW]
         int *ipiv = red_idx + NW;                                   // [16]
         double *uinv = u12s;
-        int *tcount = tmeta, *trow = tmeta + 1, *tsrc = tmeta + 1 + kMaxTouched;
         for (int j = 0; j < npan; ++j) {
+#ifdef MPCX_LU_STAMPS
+            double *stamps = p.X + (size_t)li * p.nr * p.nrhs + 4 * j;
+            if (tid == 0) stamps[0] = (double)wall_clock64();
+#endif
             const int k0 = j * kNB;
             double *gcol = A + (size_t)k0 * nrp;  // the block's 16 columns are one contiguous run of the workspace
-            for (int e = tid; e < kNB * nrp; e += THREADS) {
-                const int c = e / nrp, row = e - c * nrp;
-                blk[c * ld + row] = gcol[e];
+            {   // the block, 16-byte pieces, eight loads in flight per thread
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                const int pairs = kNB * nrp / 2;
+                for (int e0 = tid; e0 < pairs; e0 += 8 * THREADS) {
+                    v2d v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = e0 + u * THREADS;
+                        v[u] = *(const v2d *)(gcol + 2 * (e < pairs ? e : 0));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = e0 + u * THREADS;
+                        if (e < pairs) {
+                            const int c = (2 * e) / nrp, row2 = 2 * e - c * nrp;
+                            *(v2d *)(blk + c * ld + row2) = v[u];
+                        }
+                    }
+                }
             }
+#ifdef MPCX_LU_STAMPS
+            __syncthreads();
+            if (tid == 0) stamps[1] = (double)wall_clock64();
+#endif
             apply_panels(j);
             __syncthreads();
-            // panel j in LDS: column by column, pivot searched in rows >= k0 + jc, every row outside the pivot block reduced
-            for (int jc = 0; jc < kNB; ++jc) {
-                double *col = blk + jc * ld;
-                const int kk = k0 + jc;
-                double best = -1.0;
-                int bi = kk;
-                for (int rr = kk + tid; rr < nrp; rr += THREADS) {
-                    double a = fabs(col[rr]);
-                    if (!(a == a)) a = INFINITY;  // a NaN must be chosen (and fail), not skipped
-                    if (a > best) { best = a; bi = rr; }
-                }
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double ob = __shfl_xor(best, off);
-                    const int oi = __shfl_xor(bi, off);
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-                }
-                if (lane == 0) { red_val[wv] = best; red_idx[wv] = bi; }
-                __syncthreads();
-                best = red_val[0];
-                bi = red_idx[0];
-#pragma unroll
-                for (int w2 = 1; w2 < NW; ++w2) {
-                    const double ob = red_val[w2];
-                    const int oi = red_idx[w2];
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-                }
-                if (!(best > 0.0) || !isfinite(best)) {  // uniform over the workgroup
-                    if (tid == 0) p.failed[li] = 1;
-                    return;
-                }
-                if (tid < kNB) {
-                    const double t = blk[tid * ld + kk];
-                    blk[tid * ld + kk] = blk[tid * ld + bi];
-                    blk[tid * ld + bi] = t;
-                    if (tid == 0) ipiv[jc] = bi;
-                }
-                __syncthreads();
-                const double inv = 1.0 / col[kk];
-                for (int rr = tid; rr < nrp; rr += THREADS) {
-                    if (rr >= k0 && rr <= kk) continue;  // the panel's earlier pivot rows keep their entry: it belongs to U11
-                    const double l = col[rr] * inv;
-                    col[rr] = l;
-#pragma unroll
-                    for (int jj = 1; jj < kNB; ++jj)
-                        if (jc + jj < kNB) blk[(jc + jj) * ld + rr] -= l * blk[(jc + jj) * ld + kk];
-                }
-                __syncthreads();
-            }
-            // what the later blocks and the right-hand sides need of this panel
-            if (tid < kNB) {  // column tid of L11^-1 by forward substitution on a unit vector, kept in LDS as it grows
-#pragma unroll 1
-                for (int i = 0; i < kNB; ++i) {
-                    double sacc = (i == tid) ? 1.0 : 0.0;
-#pragma unroll 5
-                    for (int q = 0; q < i; ++q) sacc -= blk[q * ld + k0 + i] * linv[q * kNB + tid];
-                    linv[i * kNB + tid] = sacc;
-                }
-            }
-            if (tid >= 128 && tid < 128 + kNB) {  // column of U11^-1 by backward substitution, kept in LDS as it grows
-                const int jc = tid - 128;
-#pragma unroll 1
-                for (int i = kNB - 1; i >= 0; --i) {
-                    double sacc = (i == jc) ? 1.0 : 0.0;
-#pragma unroll 5
-                    for (int q = kNB - 1; q > i; --q) sacc -= blk[q * ld + k0 + i] * uinv[q * kNB + jc];
-                    uinv[i * kNB + jc] = sacc / blk[i * ld + k0 + i];
-                }
-            }
-            if (tid == 64) {  // net effect of the 16 exchanges: which rows end up with whose old content
-                int n = kNB;
-                for (int q = 0; q < kNB; ++q) { trow[q] = k0 + q; tsrc[q] = k0 + q; }
-                for (int jc = 0; jc < kNB; ++jc) {
-                    const int bq = ipiv[jc];
-                    if (bq == k0 + jc) continue;
-                    int ib = -1;
-                    for (int q = 0; q < n; ++q)
-                        if (trow[q] == bq) ib = q;
-                    if (ib < 0) { ib = n; trow[n] = bq; tsrc[n] = bq; ++n; }
-                    const int t = tsrc[jc];
-                    tsrc[jc] = tsrc[ib];
-                    tsrc[ib] = t;
-                }
-                *tcount = n;
-            }
-            __syncthreads();
-            for (int e = tid; e < kNB * nrp; e += THREADS) {
-                const int c = e / nrp, row = e - c * nrp;
-                gcol[e] = blk[c * ld + row];
-            }
-            {
-                double *mt = meta + (size_t)j * kMetaDoubles;
-                if (tid < kNB * kNB) { mt[tid] = linv[tid]; mt[kNB * kNB + tid] = uinv[tid]; }
-                if (tid < 1 + 2 * kMaxTouched) ((int *)(mt + kMetaInts))[tid] = tmeta[tid];
+#ifdef MPCX_LU_STAMPS
+            if (tid == 0) stamps[2] = (double)wall_clock64();
+#endif
+            if (!factor_block<THREADS, (kRhsMaxRows + THREADS - 1) / THREADS>(blk, ld, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv, gcol,
+                                       meta + (size_t)j * kMetaDoubles)) {
+                if (tid == 0) p.failed[li] = 1;
+                return;
             }
             // the next blocks stream this panel back through the vector cache: make the stores visible device-wide and
             // drop what the cache holds of these lines from the block's load
             __threadfence();
             __syncthreads();
+#ifdef MPCX_LU_STAMPS
+            if (tid == 0) stamps[3] = (double)wall_clock64();
+#endif
         }
         return;
     }
@@ -603,14 +640,15 @@ int launch_apply(const RhsArgs &ra, size_t lds, hipStream_t s) {
     return 0;
 }
 
-constexpr int kRhsMaxRows = 8 * 10 * kNB;  // the widest variant: 8 wavefronts x 10 tiles
 
 template <bool FACTOR>
 int launch_apply_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
     const int npan = ra.nrp / kNB;
     constexpr bool DB = true;
-    if (npan <= 8) return launch_apply<256, 2, DB, FACTOR>(ra, lds, s);
-    if (npan <= 16) return launch_apply<256, 4, DB, FACTOR>(ra, lds, s);
+    if constexpr (!FACTOR) {  // (H of up to 256 rows is factored by lu_block_kernel)
+        if (npan <= 8) return launch_apply<256, 2, DB, FACTOR>(ra, lds, s);
+        if (npan <= 16) return launch_apply<256, 4, DB, FACTOR>(ra, lds, s);
+    }
     if (npan <= 32) return launch_apply<512, 4, DB, FACTOR>(ra, lds, s);
     if (npan <= 56) return launch_apply<512, 7, DB, FACTOR>(ra, lds, s);
     return launch_apply<512, 10, false, FACTOR>(ra, lds, s);
@@ -620,7 +658,6 @@ size_t rhs_lds_bytes(int nrp) {  // block, U12 / U11^-1, L11^-1, exchange lists,
     return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2 + 16) * sizeof(double) + sizeof(int) * (16 + kNB);
 }
 
-constexpr int kSmallRows = 256;  // up to here H is factored right-looking by lu_block_kernel, beyond left-looking
 bool left_looking(int nrp) { return nrp > kSmallRows; }
 
 size_t lu_lds_bytes(int nrp) {  // lu_block_kernel
@@ -674,6 +711,9 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         const long long total = count * (long long)((nrhs + kNB - 1) / kNB), per_xcd = (total + 7) / 8;
         if (per_xcd * 8 > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
         ra.total = total;
+#ifdef MPCX_LU_STAMPS
+        if (left_looking(nrp)) continue;  // diagnostic build: the factorisation's time stamps stay in X
+#endif
         if (total > 0) {
             const int rc = launch_apply_any<false>(ra, rhs_bytes, s);
             if (rc != 0) return rc;
