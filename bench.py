@@ -439,7 +439,8 @@ def main():
 # extra configurations of the default run: (workload, op, f override, v override)
 ALSO = (("msd", "qp", 0, 0), ("quadrotor", "qp", 0, 0), ("long", "qp", 0, 0),
         ("quadrotor", "qp", 50, 25), ("long", "qp", 400, 200),
-        ("msd", "rollout", 0, 0), ("two_mass", "rollout", 0, 0), ("quadrotor", "rollout", 0, 0))
+        ("msd", "rollout", 0, 0), ("two_mass", "rollout", 0, 0), ("quadrotor", "rollout", 0, 0),
+        ("two_mass", "gain", 0, 0), ("two_mass", "loop", 0, 0), ("quadrotor", "gain", 0, 0), ("long", "gain", 0, 0))
 
 
 def _mfma_insts(m, r, f, v, per_gpu, symmetric=False):
