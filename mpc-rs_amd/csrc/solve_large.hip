@@ -93,7 +93,14 @@ __global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p) {
 // waited behind the prefetched loads of the next panel.
 template <int THREADS, int RPT>
 __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, double *linv, double *uinv, int *tmeta,
-                                          double *red_val, int *red_idx, int *ipiv, double *gcol, double *mt) {
+                                          double *red_val, int *red_idx, int *ipiv, double *gcol, double *mt
+#ifdef MPCX_LU_STAMPS
+                                          , double *dbg
+#define FSTAMP(k) do { if (threadIdx.x == 0 && dbg) dbg[k] = (double)wall_clock64(); } while (0)
+#else
+#define FSTAMP(k) do {} while (0)
+#endif
+                                          ) {
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int *tcount = tmeta, *trow = tmeta + 1, *tsrc = tmeta + 1 + kMaxTouched;
@@ -114,6 +121,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
     }
     double *pbuf = linv;  // the pivot row of the current column (L11^-1 is formed after the last column)
     bool failed = false;  // uniform over the workgroup
+    FSTAMP(0);
     static_for<kNB>([&](auto JC) __attribute__((always_inline)) {
         constexpr int jc = decltype(JC)::value;  // a constant in every pass: the rows stay in registers
         if (failed) return;
@@ -168,6 +176,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
 #pragma unroll
             for (int c = jc + 1; c < kNB; ++c) a[u][c] -= l * pv[c];
         }
+        FSTAMP(1 + jc);
     });
     if (failed) return false;
     __syncthreads();  // (the last column's readers of pbuf are done: it becomes L11^-1 below)
@@ -179,6 +188,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
         }
     }
     __syncthreads();
+    FSTAMP(17);
     // What the later blocks and the right-hand sides need of this panel, three wavefronts side by side:
     if (tid < kNB) {  // column tid of L11^-1 by forward substitution on a unit vector (every read of the panel issued first)
         double x[kNB];
@@ -234,6 +244,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
         if (lane == 0) *tcount = nt;
     }
     __syncthreads();
+    FSTAMP(18);
     // the block goes back to the workspace (one contiguous run), 16-byte pieces, every LDS read of a round issued first
     {
         typedef double v2d __attribute__((ext_vector_type(2)));
@@ -254,6 +265,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
     }
     if (tid < kNB * kNB) { mt[tid] = linv[tid]; mt[kNB * kNB + tid] = uinv[tid]; }
     if (tid < 1 + 2 * kMaxTouched) ((int *)(mt + kMetaInts))[tid] = tmeta[tid];
+    FSTAMP(19);
     return true;
 }
 
@@ -290,7 +302,11 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
         //    U11^-1 and the net effect of the 16 exchanges (which rows end up with whose old content)
         if (!factor_block<kThreads, kSmallRows / kThreads>(panel, nrp, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv,
                                                            A + (size_t)k0 * nrp,
-                                                           p.meta + ((size_t)blockIdx.x * (nrp / kNB) + k0 / kNB) * kMetaDoubles)) {
+                                                           p.meta + ((size_t)blockIdx.x * (nrp / kNB) + k0 / kNB) * kMetaDoubles
+#ifdef MPCX_LU_STAMPS
+                                                           , nullptr
+#endif
+                                                           )) {
             if (tid == 0) p.failed[blockIdx.x] = 1;  // uniform over the workgroup
             return;
         }
@@ -582,13 +598,17 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
             if (tid == 0) stamps[2] = (double)wall_clock64();
 #endif
             if (!factor_block<THREADS, (kRhsMaxRows + THREADS - 1) / THREADS>(blk, ld, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv, gcol,
-                                       meta + (size_t)j * kMetaDoubles)) {
+                                       meta + (size_t)j * kMetaDoubles
+#ifdef MPCX_LU_STAMPS
+                                       , p.X + (size_t)li * p.nr * p.nrhs + 4 * npan + 20 * j
+#endif
+                                       )) {
                 if (tid == 0) p.failed[li] = 1;
                 return;
             }
-            // the next blocks stream this panel back through the vector cache: make the stores visible device-wide and
-            // drop what the cache holds of these lines from the block's load
-            __threadfence();
+            // The next blocks stream this panel back, and only this workgroup does: the barrier (a workgroup-scope
+            // release / acquire over global memory as well) is all the ordering that takes.  A device-scope fence here
+            // would write the whole L2's dirty lines back to memory once per block.
             __syncthreads();
 #ifdef MPCX_LU_STAMPS
             if (tid == 0) stamps[3] = (double)wall_clock64();

@@ -30,3 +30,8 @@ for j in (1, 2, 5, 10, 20, 30, 40, npan - 1):
     if j < npan:
         print("block %3d: load %6.2f  apply %7.2f (%.2f us per panel)  factor+store %6.2f" %
               (j, load[:, j].mean(), apply_[:, j].mean(), apply_[:, j].mean() / max(j, 1), fact[:, j].mean()))
+fs = gain.cpu().numpy().reshape(count, VM * FR)[:, 4 * npan: 4 * npan + 20 * npan].reshape(count, npan, 20) / 100.0
+d_ = np.diff(fs, axis=2).mean(axis=0)  # (npan, 19)
+for j in (1, 10, 25, 40):
+    if j < npan:
+        print("block %3d columns: " % j + " ".join("%.1f" % x for x in d_[j, :16]) + "  | rows back %.1f  inverses+lists %.1f  store+desc %.1f" % tuple(d_[j, 16:19]))
