@@ -491,10 +491,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
     }
     auto panel_step = [&](int pn, int upto, double(&cur)[MT][4], double(&nxt)[MT][4]) __attribute__((always_inline)) {
         if ((MPCX_RHS_ABLATE & 2) && pn >= 0) return;
+        // (The barriers of a step order LDS traffic only: a __syncthreads() would also wait for the multipliers that were
+        // just requested for the next panel.)
         const int k0 = pn * kNB;
         if (tid < kNB * kNB) linv[tid] = m_linv;
         if (tid < 1 + 2 * kMaxTouched) tmeta[tid] = m_int;
-        __syncthreads();  // also orders the previous panel's updates (and the initial load) before the reads below
+        lds_barrier();  // also orders the previous panel's updates (and the initial load) before the reads below
         if (pn + 1 < upto) {
             fetch_meta(pn + 1);
             if (DB) fetch_multipliers(pn + 1, nxt);
@@ -509,13 +511,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
             for (int k = 0; k < kNB; ++k) uv = fma(linv[i * kNB + k], blk[c * ld + tmeta[1 + kMaxTouched + k]], uv);
             if (kNB + i < ntouched) moved = blk[(size_t)c * ld + tmeta[1 + kMaxTouched + kNB + i]];
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < kNB * kNB) {
             blk[(size_t)c * ld + k0 + i] = uv;
             u12s[i * kNB + c] = uv;
             if (kNB + i < ntouched) blk[(size_t)c * ld + tmeta[1 + kNB + i]] = moved;
         }
-        __syncthreads();
+        lds_barrier();
         d4 nu;
 #pragma unroll
         for (int q = 0; q < 4; ++q) nu[q] = -u12s[(kq + 4 * q) * kNB + l15];
