@@ -104,7 +104,8 @@ def test_reference_horizon_rows_in_registers(ctx, il, batch):
 
 
 @pytest.mark.parametrize("vm,m,fr,r,il", [(65, 1, 70, 1, 1), (100, 2, 150, 3, 1), (130, 1, 140, 1, 0), (200, 4, 600, 12, 1), (48, 1, 500, 1, 1),
-                                          (300, 2, 320, 2, 1), (530, 1, 530, 1, 1), (904, 2, 1356, 3, 1)])
+                                          (300, 2, 320, 2, 1), (530, 1, 530, 1, 1), (904, 2, 1356, 3, 1),
+                                          (80, 2, 800, 20, 1), (272, 4, 2176, 32, 0)])  # weight blocks too wide for the LDS copy
 def test_large_systems_blocked_solver(ctx, vm, m, fr, r, il):
     """Beyond 64 unknowns (or right-hand sides that do not fit LDS): the blocked solver on a device workspace."""
     rng = np.random.default_rng(vm + fr)
