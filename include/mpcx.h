@@ -166,7 +166,10 @@ int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, 
  * `info` (int32 per instance, plain array of `batch` entries, may be NULL) is 0 on success and 1 where the reference
  * returns Err("Matrix inversion failed") (controller.rs:93-95): an exactly zero or non-finite pivot; the outputs of
  * such an instance are NaN.  The call itself still returns MPCX_OK.  H, fvec, Gamma, u_seq, gain use dims->interleave.
- * Limit: (v m) (v m + columns of the right-hand side) doubles must fit the 160 KB of LDS, else MPCX_ERR_UNSUPPORTED.
+ * Limits: v m <= 1232 unknowns (a block of 16 columns of all rows has to fit the 160 KB of LDS); systems that do not
+ * fit LDS whole go through a device workspace the context owns ((v m)^2 doubles per instance in flight; it grows on
+ * demand, see mpcx_reserve); there the r x r weight block of mpcx_qp_gain is limited to r <= 64.  Beyond these:
+ * MPCX_ERR_UNSUPPORTED.
  */
 int mpcx_qp_solve_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *fvec, double *u_seq,
                       int32_t *info);

@@ -1,4 +1,4 @@
-// Solve with the condensed Hessian for systems too large for LDS (v m from 65 up to about 1200 unknowns): blocked
+// Solve with the condensed Hessian for systems too large for LDS (v m from 65 up to 1232 unknowns): blocked
 // elimination with partial pivoting, H held in a device workspace (one workgroup per instance) and the right-hand
 // sides in LDS (one workgroup per instance and 16 columns), updates on the FP64 matrix cores.
 //

@@ -145,3 +145,21 @@ def test_large_singular_is_flagged(ctx, vm):
     assert np.all(np.isnan(u[1])) and np.all(np.isnan(u[2]))
     ref = np.stack([-np.linalg.solve(H[b], fv[b]) for b in (0, 3)])
     assert rel_fro(u[[0, 3]], ref) <= 1e-10
+
+
+def test_largest_system_and_the_first_refused(ctx):
+    """1232 unknowns is the largest system the blocked solver takes (a block of 16 columns of all rows in LDS); one more
+    is refused with MPCX_ERR_UNSUPPORTED instead of being attempted."""
+    from mpc_rs_amd import ffi
+    rng = np.random.default_rng(1232)
+    vm, batch = 1232, 2
+    H = rng.standard_normal((batch, vm, vm)) + 30.0 * np.eye(vm)
+    H[:, 5, :] *= 1e-2
+    fv = rng.standard_normal((batch, vm))
+    u, info = ctx.qp_solve(H, fv, 1)
+    assert np.all(info == 0)
+    ref = np.stack([-np.linalg.solve(H[b], fv[b]) for b in range(batch)])
+    assert rel_fro(u, ref) <= 1e-11 * max(np.linalg.cond(h) for h in H)
+    with pytest.raises(ffi.MpcxError) as err:
+        ctx.qp_solve(rng.standard_normal((1, vm + 1, vm + 1)), rng.standard_normal((1, vm + 1)), 1)
+    assert err.value.code == -4  # MPCX_ERR_UNSUPPORTED
