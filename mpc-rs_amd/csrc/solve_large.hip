@@ -293,9 +293,18 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
 
     for (int k0 = 0; k0 < nrp; k0 += kNB) {
         // 1. panel -> LDS (16 adjacent columns are one contiguous run of the workspace)
-        {
-            const double *src = A + (size_t)k0 * nrp;
-            for (int e = tid; e < kNB * nrp; e += kThreads) panel[e] = src[e];
+        {   // 16-byte pieces, eight loads in flight per thread (one memory latency per round, not one per element)
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d *src = (const v2d *)(A + (size_t)k0 * nrp);
+            const int pairs = kNB * nrp / 2;
+            for (int e0 = tid; e0 < pairs; e0 += 8 * kThreads) {
+                v2d v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[e0 + u * kThreads < pairs ? e0 + u * kThreads : 0];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * kThreads < pairs) ((v2d *)panel)[e0 + u * kThreads] = v[u];
+            }
         }
         __syncthreads();
         // 2. factored in LDS; the panel goes back to the workspace (U11 is needed at the end) together with L11^-1,
@@ -346,11 +355,21 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
             const int pidx = k0 / kNB, nt = nrp / kNB - 1;
             double *cbase = A + (size_t)(c0 + (lane >> 4)) * nrp + (lane & 15);  // + r0, + 4 q columns
             auto row0 = [&](int t) { return (t < pidx ? t : t + 1) * kNB; };
+            // The next tile is requested before the current one is stored: a wavefront's loads and stores retire through
+            // one in-order counter, so a load issued behind a store also waits for that store to complete.
+            d4 nxt = {0.0, 0.0, 0.0, 0.0};
+            if (nt > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nxt[q] = cbase[(size_t)(4 * q) * nrp + row0(0)];
+            }
             for (int t = 0; t < nt; ++t) {
                 const int r0 = row0(t);
-                d4 acc;
+                d4 acc = nxt;
+                if (t + 1 < nt) {
+                    const int r1 = row0(t + 1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = cbase[(size_t)(4 * q) * nrp + r0];
+                    for (int q = 0; q < 4; ++q) nxt[q] = cbase[(size_t)(4 * q) * nrp + r1];
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double lb = panel[(size_t)((lane >> 4) + 4 * q) * nrp + r0 + (lane & 15)];
