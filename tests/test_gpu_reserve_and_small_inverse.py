@@ -15,7 +15,16 @@ from oracle import oracle_ffi as orc
 pytestmark = pytest.mark.gpu
 
 
-def test_reserve_then_dev_calls_do_not_allocate(ctx):
+def test_reserve_then_dev_calls_do_not_allocate():
+    # a context of its own: the session's may already hold a scratch area larger than anything asked for here
+    ctx = ffi.Context(0)
+    try:
+        _reserve_then_dev_calls(ctx)
+    finally:
+        ctx.close()
+
+
+def _reserve_then_dev_calls(ctx):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     n, m, r, f, v = 8, 2, 2, 80, 80  # 160 unknowns: blocked solver workspace; n = 8: general discretisation
