@@ -546,32 +546,53 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             cur ^= 1;
             lds_barrier();
         }
-        // Blocks: D[c][rho] = sum_q R_h[q][c] . (C A^lo)[rho][q],  R_h = A^(Lp h + 1) (Phi) or sY[h] (G and s)
+        // Blocks: D[c][rho] = sum_q R_h[q][c] . (C A^lo)[rho][q],  R_h = A^(Lp h + 1) (Phi) or sY[h] (G and s).  An item is
+        // one tile of 16 rows rho for one h: its (C A^lo) operand is read once and serves the Phi product and the G / s one.
         {
             const int RT = (Lp * r + 15) / 16;
             const int cols_gs = m + (p.fvec ? 1 : 0), CT = (cols_gs + 15) / 16;  // column tiles of the G / s product
-            const int kinds = (gPhi ? 1 : 0) + CT;                                // Phi has one column tile (n <= 16)
-            int cntr = 0;
-            for (int h = 0; h < nh; ++h)
-            for (int rt = 0; rt < RT; ++rt)
-            for (int kind = 0; kind < kinds; ++kind) {
-                if ((cntr++ % NWV) != wave) continue;
-                const bool is_phi = gPhi && kind == 0;
-                const int ct = is_phi ? 0 : kind - (gPhi ? 1 : 0);
-                const double *R = (is_phi ? sX + h * nn : sY + h * n * m1) + ct * 16 * n;
-                const int ncol = (is_phi ? n : cols_gs) - ct * 16;
-                const d4 acc = tile(sTC, RP, rt * 16, 16, R, ncol < 16 ? ncol : 16);
-                const int rho = rt * 16 + l15, row = Lp * h * r + rho;
-                if (rho < Lp * r && row < FR) {
+            auto prod = [&](const double *R, int ncol, const double (&bv)[kTabN / 4]) -> d4 {
+                double av[kTabN / 4];
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int c = ct * 16 + kq + 4 * reg;
-                        if (is_phi) {
-                            if (c < n) gPhi[(long long)c * FR + row] = acc[reg];
-                        } else if (c < m) {
-                            sG[c * FR + row] = acc[reg];
-                        } else if (c == m && p.fvec) {
-                            sSr[row] = acc[reg] - sSr[row];
+                for (int ks = 0; ks < kTabN / 4; ++ks) {
+                    const int q = 4 * ks + kq;
+                    const double a0 = R[(l15 < ncol ? l15 : 0) * n + (q < n ? q : 0)];
+                    av[ks] = (q < n && l15 < ncol) ? a0 : 0.0;
+                }
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < kTabN / 4; ++ks)
+                    if (ks < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+                return acc;
+            };
+            for (int it = wave; it < nh * RT; it += NWV) {
+                const int h = it / RT, rt = it - h * RT;  // wave-uniform
+                double bv[kTabN / 4];
+#pragma unroll
+                for (int ks = 0; ks < kTabN / 4; ++ks) {
+                    const int q = 4 * ks + kq;
+                    const double b0 = sTC[(q < n ? q : 0) * RP + rt * 16 + l15];
+                    bv[ks] = (q < n) ? b0 : 0.0;
+                }
+                const int rho = rt * 16 + l15, row = Lp * h * r + rho;
+                const bool live = rho < Lp * r && row < FR;
+                if (gPhi) {
+                    const d4 acc = prod(sX + h * nn, n, bv);
+                    if (live) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            if (kq + 4 * reg < n) gPhi[(long long)(kq + 4 * reg) * FR + row] = acc[reg];
+                    }
+                }
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int ncol = cols_gs - ct * 16;
+                    const d4 acc = prod(sY + h * n * m1 + ct * 16 * n, ncol < 16 ? ncol : 16, bv);
+                    if (live) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int c = ct * 16 + kq + 4 * reg;
+                            if (c < m) sG[c * FR + row] = acc[reg];
+                            else if (c == m && p.fvec) sSr[row] = acc[reg] - sSr[row];
                         }
                     }
                 }
