@@ -42,7 +42,7 @@ constexpr int kWgBlock = kCompute + 64 * kLoaders;
 
 struct WgLds {
     // offsets in doubles into the dynamic LDS buffer
-    int G, S, QG, QS, A, B, C, x0, Q, Wst, Pst, Sr, Z, Pow, Hp, W3r, Tab, total;
+    int G, S, QG, QS, Cnt, A, B, C, x0, Q, Wst, Pst, Sr, Z, Pow, Hp, W3r, Tab, Vcol, total;
 };
 
 // Power tables of the Markov / Phi construction (plants with n <= kTabN states).  With k = Lp hi + lo (Lp a power of
@@ -82,6 +82,7 @@ __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v
     L.S = o; o += m * nl * r;    // [c][j*r + a] = S_j[a][c]
     L.QG = o; o += m * fr;       // Q G_k, same indexing as G
     L.QS = o; o += m * nl * r;   // Q S_j
+    L.Cnt = o; o += 2;           // work counter of the held-input sums (an int)
     const int u = o;
     L.A = o; o += n * n;
     L.B = o; o += n * m;
@@ -99,7 +100,18 @@ __host__ __device__ inline WgLds wg_lds_layout(int n, int m, int r, int f, int v
     o = u;
     L.Hp = o; o += 2 * (v + 1) * m * m;  // column block of the swept Gram matrix, ping-pong: [slot][i*m + j][a], a = 0..v
     L.W3r = o; o += 2 * v * m * m;       // ring of two column blocks of W3: [slot][j][row]
-    L.Tab = o; o += (f > v) ? (v + 1) * m * m : 0;  // held-input case only: the virtual block row, [i*m + j][b']
+    // Held inputs (f > v): the virtual block row, [i*m + j][b'].  Where the border is summed on the matrix cores
+    // (2 m <= 16) the sums run beside fvec and the Gamma stores, i.e. while the inputs and z are still live: the
+    // virtual row and the virtual column (Vcol, the "previous column" of the first sweep step) then lie past both uses
+    // of the shared space.
+    L.Vcol = -1;
+    if (f > v && 2 * m <= 16) {
+        o = o > end1 ? o : end1;
+        L.Tab = o; o += (v + 1) * m * m;
+        L.Vcol = o; o += (v + 1) * m * m;
+    } else {
+        L.Tab = o; o += (f > v) ? (v + 1) * m * m : 0;
+    }
     L.total = o > end1 ? o : end1;
     return L;
 }
@@ -149,9 +161,9 @@ __device__ inline double h_direct(const double *sG, const double *sS, const doub
 // straight to memory with their share of W3 (the sweep skips those positions).
 typedef double d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *sS, const double *sQG, const double *sQS,
-                                               double *vcol, double *vrow, double *gH, const double *gW3, int m, int r,
-                                               int f, int v, int tid) {
-    const int wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4, nwaves = kWgBlock >> 6;
+                                               double *vcol, double *vrow, double *gH, const double *gW3, int *next_item,
+                                               int m, int r, int f, int v, int tid) {
+    const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int FR = f * r, nl = f - v + 1, K = nl * r, VM = v * m, ldh = v + 1;
     const int ND = 16 / (2 * m), NQ = (v + ND - 1) / ND;        // values of d per operand row, operand row groups
     const int rows = (NQ + 1) * m, nt = (rows + 15) >> 4;       // the last m rows are the S rows of the corner
@@ -163,8 +175,12 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
     const int koff = dd * r, kend = koff + (bg ? K - r : K);    // this column is non-zero for koff <= k' < kend
     const double *b1 = (bg ? sQG + jb * FR : sQS + jb * K) - koff;
     const double *b2 = (bg ? sG + jb * FR : sS + jb * K) - koff;
-    // work item = (tile of 16 operand rows, which of the two products): no two items share an operand read
-    for (int item = wave; item < 2 * nt; item += nwaves) {
+    // work item = (tile of 16 operand rows, which of the two products): no two items share an operand read.  Whichever
+    // wavefront is free takes the next one (the callers arrive at different times: some come from fvec, some from
+    // the Gamma stores, some straight from the weighting phase).
+    for (;;) {
+        const int item = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(next_item, 1) : 0);
+        if (item >= 2 * nt) break;
         const int tile = item >> 1;
         const bool second = item & 1;  // Z2: Hankel operand from Q G, right operand [G | S]
         const int R = tile * 16 + l15;
@@ -196,7 +212,7 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
             }
             w3v[reg] = eg[reg] >= 0 ? gW3[eg[reg]] : 0.0;
         }
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};  // two chains: no product waits for the one before
         for (int k0 = 0; k0 < Kx; k0 += 16) {  // four steps of four per round: the eight LDS reads are in flight together
             double x[4], y[4];
 #pragma unroll
@@ -208,8 +224,12 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
                 y[u] = ck ? yv : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], acc, 0, 0, 0);
+            for (int u = 0; u < 4; u += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u + 1], y[u + 1], acc1, 0, 0, 0);
+            }
         }
+        acc += acc1;
         // D[i][j]: this lane holds column j = l15 and rows i = kq + 4 reg of the tile
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -221,6 +241,90 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
             }
             if (eg[reg] >= 0) gH[eg[reg]] = acc[reg] + w3v[reg];
         }
+    }
+}
+
+// fvec = Gamma^T z on the matrix cores.  Column (k, c) of Gamma, k < v-1, is the Markov vector c shifted down by k r, so
+//     fvec[k m + c] = sum_t G[c][t] . z[t + k r]          (t < f r - k r)
+// is a product with a shifted (Hankel) operand in z: operand row kg holds z[kg ND r + t'], and column (dd, c) of the other
+// operand is G[c] delayed by dd r (ND = 16 / m consecutive shifts share an operand row, so all 16 columns of
+// v_mfma_f64_16x16x4_f64 are used); D[kg][(dd, c)] = fvec[(kg ND + dd) m + c].  Two LDS reads feed 1 024 multiply-adds
+// where the per-column dot products read two values per multiply-add.  The output is tiny (v m values) and the
+// contraction long, so the wavefronts split the contraction index: `chunks` partial tiles per 16 operand rows go to
+// LDS and are added in a fixed order afterwards.  The held-input column (k = v-1, cumulated vector S in place of G)
+// is cut into 64 / m slices summed by one wavefront, likewise added afterwards.
+// fvec_chunks: partial tiles per operand-row tile that fit `cap` doubles of LDS; 0: use the dot products instead.
+__host__ __device__ inline int fvec_chunks(int m, int v, int cap) {
+    if (m > 16 || v < 2) return 0;
+    const int ND = 16 / m, NQ = (v - 1 + ND - 1) / ND, tiles = (NQ + 15) >> 4;
+    int ch = kLoaders / tiles;
+    if (ch < 1) ch = 1;
+    while (ch > 1 && ch * NQ * 16 + 64 > cap) --ch;
+    return (ch * NQ * 16 + 64 <= cap) ? ch : 0;
+}
+__device__ __forceinline__ void fvec_partials(const double *sG, const double *sS, const double *sZ, double *part,
+                                              int chunks, int m, int r, int f, int v, int lw, int lane) {
+    const int l15 = lane & 15, kq = lane >> 4, FR = f * r, nl = f - v + 1;
+    const int ND = 16 / m, NQ = (v - 1 + ND - 1) / ND, tiles = (NQ + 15) >> 4;
+    const int ddr = l15 / m;
+    const bool bok = ddr < ND;
+    const int dd = bok ? ddr : 0, c = bok ? l15 - dd * m : 0;
+    const double *pb = sG + c * FR - dd * r;  // pb[t'] = G[c][t' - dd r]
+    for (int item = lw; item < tiles * chunks; item += kLoaders) {
+        const int T = item / chunks, ch = item - T * chunks;
+        const int kg = T * 16 + l15;
+        const bool rowok = kg < NQ;
+        const int zoff = (rowok ? kg : 0) * ND * r;  // operand row: z[zoff + t'], zero from f r on
+        const int Kx = FR - T * 16 * ND * r + (ND - 1) * r;
+        const int rounds = (Kx + 15) >> 4;
+        const int r0 = rounds * ch / chunks, r1 = rounds * (ch + 1) / chunks;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int rd = r0; rd < r1; ++rd) {
+            double x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = rd * 16 + 4 * u + kq;
+                const bool ak = rowok && zoff + t < FR, bk = bok && t >= dd * r && t - dd * r < FR;
+                const double xv = sZ[ak ? zoff + t : 0], yv = pb[bk ? t : dd * r];
+                x[u] = ak ? xv : 0.0;
+                y[u] = bk ? yv : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u + 1], y[u + 1], acc1, 0, 0, 0);
+            }
+        }
+        acc += acc1;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {  // D[i][j]: this lane holds column j = l15 and rows i = kq + 4 reg
+            const int kgi = T * 16 + kq + 4 * reg;
+            if (kgi < NQ) part[(ch * NQ + kgi) * 16 + l15] = acc[reg];
+        }
+    }
+    if (lw == kLoaders - 1) {  // held-input column: slice sl of S[c] . z[(v-1) r ...]
+        const int nsl = 64 / m, sl = lane / m, cc = lane - sl * m, len = nl * r, seg = (len + nsl - 1) / nsl;
+        double sum = 0.0;
+        if (sl < nsl) {
+            const double *src = sS + cc * len, *zz = sZ + (v - 1) * r;
+            const int t1 = (sl + 1) * seg < len ? (sl + 1) * seg : len;
+            for (int t = sl * seg; t < t1; ++t) sum += src[t] * zz[t];
+        }
+        part[chunks * NQ * 16 + lane] = sum;
+    }
+}
+__device__ __forceinline__ void fvec_finish(const double *part, double *gf, int chunks, int m, int v, int tid) {
+    const int ND = 16 / m, NQ = (v - 1 + ND - 1) / ND, nsl = 64 / m;
+    for (int idx = tid; idx < v * m; idx += kWgBlock) {
+        const int k = idx / m, c = idx - k * m;
+        double sum = 0.0;
+        if (k < v - 1) {
+            const int kg = k / ND, dd = k - kg * ND;
+            for (int ch = 0; ch < chunks; ++ch) sum += part[(ch * NQ + kg) * 16 + dd * m + c];
+        } else {
+            for (int sl = 0; sl < nsl; ++sl) sum += part[chunks * NQ * 16 + sl * m + c];
+        }
+        gf[idx] = sum;
     }
 }
 
@@ -419,21 +523,29 @@ __global__ __launch_bounds__(256) void w3_band_kernel(const double *__restrict__
 // from the specialised sweep, and with them a dozen live registers.
 template <int HM, int HR, int ITEMS, bool HELD>
 __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     // Diagnostic build (-DMPCX_WG_STAMPS, see tools/probe_phases.py): thread 0 records the 100 MHz wall clock at the
     // phase boundaries into the caller's fvec buffer (v m >= 10 doubles per instance), and fvec itself is not computed.
-#ifdef MPCX_WG_STAMPS
+#ifdef MPCX_WG_STAMPS2
+    double *stampbuf = p.Phi + (long long)blockIdx.x * p.f * (HR ? HR : p.r) * p.n;
+    p.Phi = nullptr;
+#define STAMP(k) do { if (threadIdx.x == 0) stampbuf[k] = (double)wall_clock64(); } while (0)
+#define LSTAMP(k) do { if (threadIdx.x == kCompute) stampbuf[k] = (double)wall_clock64(); } while (0)
+#elif defined(MPCX_WG_STAMPS)
     double *stampbuf = p.fvec + (long long)blockIdx.x * p.v * (HM ? HM : p.m);
     p.fvec = nullptr;
 #define STAMP(k) do { if (threadIdx.x == 0) stampbuf[k] = (double)wall_clock64(); } while (0)
 #else
 #define STAMP(k) do {} while (0)
 #endif
+#ifndef LSTAMP
+#define LSTAMP(k) do {} while (0)
+#endif
     STAMP(0);
+    const long long b = blockIdx.x;
     const int tid = threadIdx.x;
     const bool loader = tid >= kCompute;  // wave-uniform: the waves after the four compute waves
     const int ltid = (tid - kCompute) & 63, lw = (tid - kCompute) >> 6;  // lane and index of the loader wave
-    const long long b = blockIdx.x;
     const int n = p.n, m = HM ? HM : p.m, r = HR ? HR : p.r, f = p.f, v = p.v;
     const int FR = f * r, VM = v * m, nl = f - v + 1;
     const WgLds L = wg_lds_layout(n, m, r, f, v);
@@ -441,6 +553,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     double *sW = lds + L.Wst, *sP = lds + L.Pst, *sG = lds + L.G, *sS = lds + L.S, *sQG = lds + L.QG;
     double *sQS = lds + L.QS, *sSr = lds + L.Sr, *sZ = lds + L.Z, *sHp = lds + L.Hp, *sW3 = lds + L.W3r;
     double *sTab = lds + L.Tab, *sAx = sx0 + n;
+    int *sCnt = (int *)(lds + L.Cnt);
 
     const double *gA = p.A + b * (long long)(n * n);
     const double *gB = p.B + b * (long long)(n * m);
@@ -448,6 +561,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     const bool need_q = p.H || p.fvec;
 
     // ---- every per-instance input goes to LDS before the first store of the workgroup ----
+    if (tid == 0) *sCnt = 0;
     for (int e = tid; e < n * n; e += kWgBlock) sA[e] = gA[e];
     const bool tables = n <= kTabN;  // wave-uniform: power tables instead of the step-by-step recurrences
     for (int e = tid; e < n * m; e += kWgBlock) { const double x = gB[e]; sB[e] = x; if (!tables) sW[e] = x; }
@@ -675,17 +789,79 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     //      the H sweep.  Workgroups that share a CU run the same phases for the same time and would stay in lockstep,
     //      all storing Gamma at once and all sweeping at once; every other resident workgroup therefore writes Gamma
     //      last, so that one workgroup's store stream overlaps the other's sweep.
-    //      Only where Gamma is at least as large as H (f r >= v m). ----
-    const bool gamma_last = p.Gamma && p.H && FR >= VM && (blockIdx.x & 1);
+    //      Only where Gamma is at least as large as H (f r >= v m), and not with held inputs (f > v): there the
+    //      other wavefronts form fvec and the held-input sums while Gamma is stored, which hides both. ----
+    const bool gamma_last = p.Gamma && p.H && FR >= VM && (blockIdx.x & 1) && !(f > v);
     auto write_gamma = [&]() {
+        // A wavefront takes a column at a time, lanes along its rows.  The LDS reads of a stretch of rows all issue
+        // before the first store (one LDS round trip per stretch, not per store instruction); rows above the block
+        // diagonal read a valid address and store zero.
         double *gG = p.Gamma + b * (long long)FR * VM;
-        const int wave = tid >> 6, lane = tid & 63, nwaves = kCompute >> 6;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = kCompute >> 6;
+        constexpr int U = 8;
+        const bool wide16 = (((FR | r) & 1) == 0) && (((uintptr_t)p.Gamma & 15) == 0);
         for (int col = wave; col < VM; col += nwaves) {
-            const int k = col / m, c = col % m;
+            const int k = col / m, c = col - k * m;
             const int shift = k * r;
-            const double *src = (k == v - 1) ? (sS + c * nl * r) : (sG + c * FR);
+            const double *src = ((k == v - 1) ? (sS + c * nl * r) : (sG + c * FR)) - shift;  // src[row], row >= shift
             double *dst = gG + (long long)col * FR;
-            for (int row = lane; row < FR; row += 64) dst[row] = (row < shift) ? 0.0 : src[row - shift];
+            if (wide16) {
+                // two rows per lane: a wavefront stores 16 bytes per lane at more than twice the rate of 8 (measured:
+                // 40 against 17 GB/s per wavefront, tools/cu_write_rate.hip).  Every count here is even, so a pair
+                // lies wholly above the diagonal block or wholly in the data, and never across the end of the column.
+                const v2d *src2 = (const v2d *)src;
+                v2d *dst2 = (v2d *)dst;
+                const int FP = FR >> 1, sp = shift >> 1;
+                const v2d zero = {0.0, 0.0};
+                constexpr int U2 = 4;
+                int p0 = 0;
+                for (; p0 + 64 * U2 <= FP; p0 += 64 * U2) {
+                    v2d x[U2];
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        const int pr = p0 + 64 * u + lane;
+                        x[u] = src2[pr < sp ? sp : pr];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        const int pr = p0 + 64 * u + lane;
+                        dst2[pr] = pr < sp ? zero : x[u];
+                    }
+                }
+                for (; p0 < FP; p0 += 64) {
+                    const int pr = p0 + lane;
+                    const v2d x = src2[pr < sp ? sp : (pr < FP ? pr : FP - 1)];
+                    if (pr < FP) dst2[pr] = pr < sp ? zero : x;
+                }
+                continue;
+            }
+            int row0 = 0;
+            for (; row0 + 64 * U <= FR; row0 += 64 * U) {
+                double x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = row0 + 64 * u + lane;
+                    x[u] = src[row < shift ? shift : row];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = row0 + 64 * u + lane;
+                    dst[row] = row < shift ? 0.0 : x[u];
+                }
+            }
+            for (; row0 < FR; row0 += 64 * 2) {
+                double x[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int row = row0 + 64 * u + lane;
+                    x[u] = src[row < shift ? shift : (row < FR ? row : FR - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int row = row0 + 64 * u + lane;
+                    if (row < FR) dst[row] = row < shift ? 0.0 : x[u];
+                }
+            }
         }
     };
     STAMP(2);
@@ -694,7 +870,13 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
 
     // ---- fvec[col] = sum_rows Gamma[row][col] Z[row], by the loader waves: they are idle until the sweep, so with
     //      Gamma requested the dot products run beside the compute waves' Gamma store stream. ----
-    if (p.fvec && loader) {
+    LSTAMP(10);
+    // (the inputs are dead by now: their LDS holds the partial tiles of the matrix-core form)
+    const int fchunks = p.fvec ? fvec_chunks(m, v, L.Z - L.A) : 0;
+    double *sPart = lds + L.A;
+    if (fchunks > 0) {
+        if (loader) fvec_partials(sG, sS, sZ, sPart, fchunks, m, r, f, v, __builtin_amdgcn_readfirstlane(lw), ltid);
+    } else if (p.fvec && loader) {
         double *gf = p.fvec + b * (long long)VM;
         for (int col = tid - kCompute; col < VM; col += 64 * kLoaders) {
             const int k = col / m, c = col % m;
@@ -715,14 +897,16 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             gf[col] = (a[0] + a[1]) + (a[2] + a[3]);
         }
     }
-
-    // ---- H, swept by column block from v-1 down to 0.  The previous column block sits in one half of sHp, the
-    //      new one goes to the other half; the loader wave streams the next block of W3 into its ring meanwhile.
-    //      sHp is indexed [i*m + j][a]: lanes along the block rows, so reads and writes are conflict-free.
-    //      What is swept is the Gram matrix Ht of the plain-shift columns, for which the recurrence holds for every
-    //      block with Ht[v][.] = 0 when f = v.  When f > v the column Ht[.][v-1] and the row Ht[v-1][.] come from two
-    //      tables, and the last block row and column of H (which involve the held-input column) are left out of the
-    //      sweep and stored after it. ----
+    LSTAMP(11);
+    const bool held = HM > 0 ? HELD : nl > 1;
+    const bool mfma_sums = p.H && held && 2 * m <= 16;
+    if (mfma_sums)
+        held_sums_mfma(sG, sS, sQG, sQS, lds + L.Vcol, sTab, p.H + b * (long long)VM * VM, p.W3, sCnt, m, r, f, v, tid);
+    LSTAMP(12);
+    if (fchunks > 0) {
+        lds_barrier();
+        fvec_finish(sPart, p.fvec + b * (long long)VM, fchunks, m, v, tid);
+    }
     STAMP(4);
     if (p.H) {
         lds_barrier();  // z and the inputs are dead: their LDS becomes the sweep's buffers
@@ -744,13 +928,12 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         // For f > v the last block row and column of H itself involve the held-input column and are not swept: they are
         // summed (with the border, on the matrix cores where 2 m <= 16) and stored before or after the sweep.
         const int bsz = m * m, ldh = v + 1, slot = bsz * ldh;
-        const bool held = HM > 0 ? HELD : nl > 1;
-        const bool mfma_sums = held && 2 * m <= 16;
         double *sVrow = sTab;
         double *gH = p.H + b * (long long)VM * VM;
-        double *first_prev = sHp + (v & 1) * slot;  // what step bb = v-1 reads as its previous column
+        // what step bb = v-1 reads as its previous column
+        double *first_prev = mfma_sums ? lds + L.Vcol : sHp + (v & 1) * slot;
         if (mfma_sums) {
-            held_sums_mfma(sG, sS, sQG, sQS, first_prev, sVrow, gH, p.W3, m, r, f, v, tid);
+            // summed above
         } else if (held) {
             for (int t = tid; t < 2 * v * bsz; t += kWgBlock) {
                 const int which = t / (v * bsz), rem = t - which * (v * bsz), blk = 1 + rem / bsz, ij = rem % bsz;
@@ -789,7 +972,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                 STAMP(6);
                 for (int bb = v - 1; bb >= 0; --bb) {
                     double *cur = sHp + (bb & 1) * slot;
-                    const double *prev = sHp + ((bb + 1) & 1) * slot;
+                    const double *prev = (bb == v - 1) ? first_prev : sHp + ((bb + 1) & 1) * slot;
                     const double *w3 = sW3 + (bb & 1) * VM * m;
                     if (bb == v / 2) STAMP(7);
                     // Three passes over the thread's items, two items at a time -- every LDS read, then the arithmetic,
@@ -856,7 +1039,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
             } else {
                 for (int bb = v - 1; bb >= 0; --bb) {
                     double *cur = sHp + (bb & 1) * slot;
-                    const double *prev = sHp + ((bb + 1) & 1) * slot;
+                    const double *prev = (bb == v - 1) ? first_prev : sHp + ((bb + 1) & 1) * slot;
                     const double *w3 = sW3 + (bb & 1) * VM * m;
                     for (int t = tid; t < VM; t += kCompute) {  // t = j * v + aa, as in the specialised sweep
                         const int j = t / v, aa = t - j * v;

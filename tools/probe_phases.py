@@ -16,11 +16,19 @@ bufs["W3"] = to(L.colmajor(d["W3"])); bufs["Q"] = to(L.colmajor(d["Q"]))
 sizes = {"Phi": f * r * n, "Gamma": f * r * v * m, "H": v * m * v * m, "fvec": v * m}
 outs = {k: torch.zeros(count * e, dtype=torch.float64, device=dev) for k, e in sizes.items()}
 dims = ffi.make_dims(n, m, r, f, v, count, 0, il)
-ptr = lambda k: outs[k].data_ptr() if (k in want or k == "fvec") else None
+ptr = lambda k: outs[k].data_ptr() if (k in want or k == "fvec" or (k == "Phi" and os.environ.get("STAMPS2"))) else None
 for _ in range(3):
     ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(), bufs["W3"].data_ptr(),
                      bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(), ptr("Phi"), ptr("Gamma"), ptr("H"), ptr("fvec"), 0)
 torch.cuda.synchronize()
+if os.environ.get("STAMPS2"):
+    raw = outs["Phi"].cpu().numpy().reshape(count, f * r * n)[:, :13]
+    mid2 = slice(count // 4, 3 * count // 4)
+    for half in (0, 1):
+        q = raw[mid2][half::2]
+        print("half", half, "loader: S,QG,Z end->fvec start %.1f  fvec %.1f  sums(loader) %.1f ; compute t0->3 %.1f, 3->4 %.1f total %.1f" % tuple(x / 100 for x in ((q[:, 10] - q[:, 2]).mean(), (q[:, 11] - q[:, 10]).mean(), (q[:, 12] - q[:, 11]).mean(), (q[:, 3] - q[:, 0]).mean(), (q[:, 4] - q[:, 3]).mean(), (q[:, 9] - q[:, 0]).mean())))
+    print("kernel span %.3f ms" % ((raw[:, 9].max() - raw[:, 0].min()) / 1e5))
+    sys.exit(0)
 st = outs["fvec"].cpu().numpy().reshape(count, v * m)[:, :10]
 names = ["load+recur", "S,QG,Z", "gamma(first)", "fvec", "sweep prep", "ga load", "sweep 1st half", "sweep 2nd half", "gamma(last)"]
 dt = np.diff(st, axis=1) / 100.0  # 100 MHz -> us
