@@ -20,7 +20,9 @@
 // (v m)^2, far larger than LDS) is streamed column block by column block into an LDS ring by four more waves
 // that never store to it: each holds its share of up to eight blocks in flight in registers, so that a fetch has
 // several sweep steps to arrive (a CU's vector-memory pipeline is in order: loads queue behind the store stream).
-// The same four waves form fvec while the compute waves write Gamma.
+// The same four waves form fvec (a Hankel product on the matrix cores) and, with held inputs, the short sums that
+// border the swept matrix, while the compute waves write Gamma (16 bytes per lane where the counts are even: a
+// wavefront sustains 40 GB/s of 16-byte stores against 17 GB/s of 8-byte ones, tools/cu_write_rate.hip).
 //
 // Reference math: src/control/controller.rs:32-44 (Phi), :46-90 (Gamma), :92-93 (H), :96 and :125-127 (fvec).
 #include <limits.h>
@@ -213,7 +215,11 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
             w3v[reg] = eg[reg] >= 0 ? gW3[eg[reg]] : 0.0;
         }
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};  // two chains: no product waits for the one before
-        for (int k0 = 0; k0 < Kx; k0 += 16) {  // four steps of four per round: the eight LDS reads are in flight together
+        // Four steps of four per round: the eight LDS reads are in flight together.  A round is masked where a live
+        // row or column can be outside its range (the delayed columns' first (ND-1) r terms; everything from K - r on);
+        // the stretch between takes plain reads at constant offsets.  (Dead rows and columns read valid, finite data
+        // there: a row or column of the product depends on its own operand row or column only.)
+        auto masked_round = [&](int k0) {
             double x[4], y[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -228,7 +234,24 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], acc, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u + 1], y[u + 1], acc1, 0, 0, 0);
             }
+        };
+        const int khead = ((ND - 1) * r + 15) & ~15;
+        int k0 = 0;
+        for (; k0 < khead && k0 < Kx; k0 += 16) masked_round(k0);
+        {
+            const double *pal = pa + kq, *pbl = pb + kq;
+            for (; k0 + 16 <= K - r; k0 += 16) {
+                double x[4], y[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { x[u] = pal[k0 + 4 * u]; y[u] = pbl[k0 + 4 * u]; }
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u + 1], y[u + 1], acc1, 0, 0, 0);
+                }
+            }
         }
+        for (; k0 < Kx; k0 += 16) masked_round(k0);
         acc += acc1;
         // D[i][j]: this lane holds column j = l15 and rows i = kq + 4 reg of the tile
 #pragma unroll
@@ -526,6 +549,8 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     extern __shared__ __align__(16) double lds[];
     // Diagnostic build (-DMPCX_WG_STAMPS, see tools/probe_phases.py): thread 0 records the 100 MHz wall clock at the
     // phase boundaries into the caller's fvec buffer (v m >= 10 doubles per instance), and fvec itself is not computed.
+    // -DMPCX_WG_STAMPS2 keeps fvec and records into the caller's Phi buffer instead (Phi is then not computed), with three
+    // more stamps taken by the first loader wave around fvec and the held-input sums (STAMPS2=1 in tools/probe_phases.py).
 #ifdef MPCX_WG_STAMPS2
     double *stampbuf = p.Phi + (long long)blockIdx.x * p.f * (HR ? HR : p.r) * p.n;
     p.Phi = nullptr;
@@ -900,7 +925,9 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     LSTAMP(11);
     const bool held = HM > 0 ? HELD : nl > 1;
     const bool mfma_sums = p.H && held && 2 * m <= 16;
-    if (mfma_sums)
+    // (a wavefront coming from the Gamma stores would take its item late and wait for the item's loads behind its
+    // own stores: with Gamma requested the sums are the other wavefronts' alone)
+    if (mfma_sums && (loader || !p.Gamma))
         held_sums_mfma(sG, sS, sQG, sQS, lds + L.Vcol, sTab, p.H + b * (long long)VM * VM, p.W3, sCnt, m, r, f, v, tid);
     LSTAMP(12);
     if (fchunks > 0) {

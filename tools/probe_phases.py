@@ -1,4 +1,5 @@
-"""Phase stamps of the workgroup QP kernel (needs a library built with -DMPCX_WG_STAMPS, e.g. tools/build_variant.sh stamps qp_wg.hip -DMPCX_WG_STAMPS, and MPCX_LIB pointing at it; diagnostic, GPU only)."""
+"""Phase stamps of the workgroup QP kernel (needs a library built with -DMPCX_WG_STAMPS, e.g. tools/build_variant.sh stamps qp_wg.hip -DMPCX_WG_STAMPS, and MPCX_LIB pointing at it; diagnostic, GPU only).
+With STAMPS2=1 in the environment and a -DMPCX_WG_STAMPS2 build: fvec is computed and the first loader wave's stamps around fvec and the held-input sums are printed (pass an output list without Phi: the stamps live in its buffer)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
