@@ -175,51 +175,52 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
     const bool bok = dd < ND, bg = jt < m;
     const int jb = bg ? jt : jt - m;
     const int koff = dd * r, kend = koff + (bg ? K - r : K);    // this column is non-zero for koff <= k' < kend
-    const double *b1 = (bg ? sQG + jb * FR : sQS + jb * K) - koff;
-    const double *b2 = (bg ? sG + jb * FR : sS + jb * K) - koff;
-    // work item = (tile of 16 operand rows, which of the two products): no two items share an operand read.  Whichever
-    // wavefront is free takes the next one (the callers arrive at different times: some come from fvec, some from
-    // the Gamma stores, some straight from the weighting phase).
+    const double *pb1 = (bg ? sQG + jb * FR : sQS + jb * K) - koff;  // Z1: right operand [Q G | Q S]
+    const double *pb2 = (bg ? sG + jb * FR : sS + jb * K) - koff;    // Z2: right operand [G | S]
+    // Work item = a tile of 16 operand rows, BOTH products: the two are independent chains, so one wavefront has
+    // twice the LDS reads in flight and four products to issue per round trip (a lone wavefront per SIMD is bound by
+    // that round trip, not by the matrix core).  Whichever wavefront is free takes the next tile.
     for (;;) {
-        const int item = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(next_item, 1) : 0);
-        if (item >= 2 * nt) break;
-        const int tile = item >> 1;
-        const bool second = item & 1;  // Z2: Hankel operand from Q G, right operand [G | S]
+        const int tile = __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(next_item, 1) : 0);
+        if (tile >= nt) break;
         const int R = tile * 16 + l15;
         const bool rowok = R < rows;
         const int dq = rowok ? R / m : 0, c = rowok ? R - dq * m : 0;
         const bool srow = (dq == NQ);
-        const double *pa = second ? (srow ? sQS + c * K : sQG + c * FR + dq * ND * r) : (srow ? sS + c * K : sG + c * FR + dq * ND * r);
-        const double *pb = second ? b2 : b1;
+        const double *pa1 = srow ? sS + c * K : sG + c * FR + dq * ND * r;    // Z1: Hankel operand from G (S for the corner)
+        const double *pa2 = srow ? sQS + c * K : sQG + c * FR + dq * ND * r;  // Z2: Hankel operand from Q G
         const int klim = srow ? K : Kx;  // (rows whose d runs past v-1 read on into the next vector: finite, discarded)
-        // where this lane's four results go: memory (with W3, read now and used after the contraction) or the border
-        double w3v[4];
-        long long eg[4];
+        // where this lane's results go: memory (with W3, read now and used after the contraction) or the border
+        double w3a[4], w3b[4];
+        int ega[4], egb[4];  // element of H (v m <= 1 232: the index fits)
         int ta[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int Ri = tile * 16 + kq + 4 * reg;
             const int dqi = Ri / m, ci = Ri - dqi * m, di = dqi * ND + dd;
-            eg[reg] = -1;
+            ega[reg] = -1;
+            egb[reg] = -1;
             ta[reg] = -1;
             if (Ri < rows && bok) {
                 if (dqi == NQ) {
-                    if (dd == 0 && !bg && !second) eg[reg] = (long long)((v - 1) * m + jb) * VM + (v - 1) * m + ci;  // corner
+                    if (dd == 0 && !bg) ega[reg] = ((v - 1) * m + jb) * VM + (v - 1) * m + ci;  // corner
                 } else if (di < v) {
                     if (bg) ta[reg] = v - di;  // a' resp. b'
-                    else if (di > 0)
-                        eg[reg] = second ? (long long)((v - 1 - di) * m + ci) * VM + (v - 1) * m + jb   // H[v-1][b][jb][ci]
-                                         : (long long)((v - 1) * m + jb) * VM + (v - 1 - di) * m + ci;  // H[a][v-1][ci][jb]
+                    else if (di > 0) {
+                        ega[reg] = ((v - 1) * m + jb) * VM + (v - 1 - di) * m + ci;  // H[a][v-1][ci][jb]
+                        egb[reg] = ((v - 1 - di) * m + ci) * VM + (v - 1) * m + jb;  // H[v-1][b][jb][ci]
+                    }
                 }
             }
-            w3v[reg] = eg[reg] >= 0 ? gW3[eg[reg]] : 0.0;
+            w3a[reg] = ega[reg] >= 0 ? gW3[ega[reg]] : 0.0;
+            w3b[reg] = egb[reg] >= 0 ? gW3[egb[reg]] : 0.0;
         }
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};  // two chains: no product waits for the one before
-        // Four steps of four per round: the eight LDS reads are in flight together.  A round is masked where a live
-        // row or column can be outside its range (the delayed columns' first (ND-1) r terms; everything from K - r on);
-        // the stretch between takes plain reads at constant offsets.  (Dead rows and columns read valid, finite data
-        // there: a row or column of the product depends on its own operand row or column only.)
-        auto masked_round = [&](int k0) {
+        d4 a0 = (d4){0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;  // two chains per product
+        // Four steps of four per round.  A round is masked where a live row or column can be outside its range (the
+        // delayed columns' first (ND-1) r terms; everything from K - r on); the stretch between takes plain reads at
+        // constant offsets.  (Dead rows and columns read valid, finite data there: a row or column of the product
+        // depends on its own operand row or column only.)
+        auto masked_half = [&](int k0, const double *pa, const double *pb, d4 &c0, d4 &c1) {
             double x[4], y[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -231,38 +232,42 @@ __device__ __forceinline__ void held_sums_mfma(const double *sG, const double *s
             }
 #pragma unroll
             for (int u = 0; u < 4; u += 2) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u + 1], y[u + 1], acc1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u + 1], y[u + 1], c1, 0, 0, 0);
             }
+        };
+        auto masked_round = [&](int k0) {
+            masked_half(k0, pa1, pb1, a0, a1);
+            masked_half(k0, pa2, pb2, b0, b1);
         };
         const int khead = ((ND - 1) * r + 15) & ~15;
         int k0 = 0;
         for (; k0 < khead && k0 < Kx; k0 += 16) masked_round(k0);
         {
-            const double *pal = pa + kq, *pbl = pb + kq;
-            for (; k0 + 16 <= K - r; k0 += 16) {
-                double x[4], y[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { x[u] = pal[k0 + 4 * u]; y[u] = pbl[k0 + 4 * u]; }
-#pragma unroll
-                for (int u = 0; u < 4; u += 2) {
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], y[u], acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u + 1], y[u + 1], acc1, 0, 0, 0);
-                }
+            const double *pa1l = pa1 + kq, *pb1l = pb1 + kq, *pa2l = pa2 + kq, *pb2l = pb2 + kq;
+            for (; k0 + 8 <= K - r; k0 += 8) {  // half rounds: eight reads, four products
+                const double x10 = pa1l[k0], x11 = pa1l[k0 + 4], y10 = pb1l[k0], y11 = pb1l[k0 + 4];
+                const double x20 = pa2l[k0], x21 = pa2l[k0 + 4], y20 = pb2l[k0], y21 = pb2l[k0 + 4];
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x10, y10, a0, 0, 0, 0);
+                b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x20, y20, b0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x11, y11, a1, 0, 0, 0);
+                b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x21, y21, b1, 0, 0, 0);
             }
         }
         for (; k0 < Kx; k0 += 16) masked_round(k0);
-        acc += acc1;
+        a0 += a1;
+        b0 += b1;
         // D[i][j]: this lane holds column j = l15 and rows i = kq + 4 reg of the tile
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int Ri = tile * 16 + kq + 4 * reg;
             const int ci = Ri % m;
             if (ta[reg] >= 0) {
-                if (second) vrow[(jb * m + ci) * ldh + ta[reg]] = acc[reg];  // Ht[v][b'][jb][ci]
-                else vcol[(ci * m + jb) * ldh + ta[reg]] = acc[reg];         // Ht[a'][v][ci][jb]
+                vcol[(ci * m + jb) * ldh + ta[reg]] = a0[reg];  // Ht[a'][v][ci][jb]
+                vrow[(jb * m + ci) * ldh + ta[reg]] = b0[reg];  // Ht[v][b'][jb][ci]
             }
-            if (eg[reg] >= 0) gH[eg[reg]] = acc[reg] + w3v[reg];
+            if (ega[reg] >= 0) gH[ega[reg]] = a0[reg] + w3a[reg];
+            if (egb[reg] >= 0) gH[egb[reg]] = b0[reg] + w3b[reg];
         }
     }
 }
@@ -587,15 +592,37 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
 
     // ---- every per-instance input goes to LDS before the first store of the workgroup ----
     if (tid == 0) *sCnt = 0;
-    for (int e = tid; e < n * n; e += kWgBlock) sA[e] = gA[e];
     const bool tables = n <= kTabN;  // wave-uniform: power tables instead of the step-by-step recurrences
-    for (int e = tid; e < n * m; e += kWgBlock) { const double x = gB[e]; sB[e] = x; if (!tables) sW[e] = x; }
-    for (int e = tid; e < r * n; e += kWgBlock) { const double x = gC[e]; sC[e] = x; if (!tables) sP[e] = x; }
-    if (p.fvec) {
-        for (int e = tid; e < n; e += kWgBlock) sx0[e] = p.x0[b * n + e];
-        for (int e = tid; e < FR; e += kWgBlock) sSr[e] = p.ref[b * (long long)FR + e];
+    if (n * n <= kWgBlock && r * n <= kWgBlock && n * m <= kWgBlock && r * r <= kWgBlock && FR <= 2 * kWgBlock) {
+        // every array fits one element per thread (ref: two): all loads issue before the first LDS write, so the
+        // workgroup waits for memory once (a load queues behind the stores of the other workgroup on the CU:
+        // microseconds each time)
+        const bool wf = p.fvec != nullptr;
+        const double *gref = wf ? p.ref + b * (long long)FR : nullptr;
+        const double va = tid < n * n ? gA[tid] : 0.0;
+        const double vb = tid < n * m ? gB[tid] : 0.0;
+        const double vc = tid < r * n ? gC[tid] : 0.0;
+        const double vq = (need_q && tid < r * r) ? p.W4[tid] : 0.0;
+        const double vx = (wf && tid < n) ? p.x0[b * n + tid] : 0.0;
+        const double vr0 = (wf && tid < FR) ? gref[tid] : 0.0;
+        const double vr1 = (wf && tid + kWgBlock < FR) ? gref[tid + kWgBlock] : 0.0;
+        if (tid < n * n) sA[tid] = va;
+        if (tid < n * m) { sB[tid] = vb; if (!tables) sW[tid] = vb; }
+        if (tid < r * n) { sC[tid] = vc; if (!tables) sP[tid] = vc; }
+        if (need_q && tid < r * r) sQ[tid] = vq;
+        if (wf && tid < n) sx0[tid] = vx;
+        if (wf && tid < FR) sSr[tid] = vr0;
+        if (wf && tid + kWgBlock < FR) sSr[tid + kWgBlock] = vr1;
+    } else {
+        for (int e = tid; e < n * n; e += kWgBlock) sA[e] = gA[e];
+        for (int e = tid; e < n * m; e += kWgBlock) { const double x = gB[e]; sB[e] = x; if (!tables) sW[e] = x; }
+        for (int e = tid; e < r * n; e += kWgBlock) { const double x = gC[e]; sC[e] = x; if (!tables) sP[e] = x; }
+        if (p.fvec) {
+            for (int e = tid; e < n; e += kWgBlock) sx0[e] = p.x0[b * n + e];
+            for (int e = tid; e < FR; e += kWgBlock) sSr[e] = p.ref[b * (long long)FR + e];
+        }
+        if (need_q) for (int e = tid; e < r * r; e += kWgBlock) sQ[e] = p.W4[e];
     }
-    if (need_q) for (int e = tid; e < r * r; e += kWgBlock) sQ[e] = p.W4[e];
     lds_barrier();
 
     // ---- recurrences: step k produces G_k (from W_k), W_(k+1) = A W_k, P_(k+1) = P_k A (P_0 = C) ----
@@ -896,6 +923,25 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     // ---- fvec[col] = sum_rows Gamma[row][col] Z[row], by the loader waves: they are idle until the sweep, so with
     //      Gamma requested the dot products run beside the compute waves' Gamma store stream. ----
     LSTAMP(10);
+    // The first column block of W3 the sweep needs (block v-1) is requested ahead of time by the loader waves and
+    // written to its ring slot when the sweep's buffers become free: its latency passes behind fvec (without held
+    // inputs) or behind the wait for the other wavefronts (with them: requested after the sums, which need the registers).
+    constexpr int kW3Pre = 8;
+    const int wcnt0 = VM * m;
+    const bool w3early = p.H && loader && wcnt0 <= kW3Pre * 64 * kLoaders;
+    double w3pre[kW3Pre];
+    auto request_w3 = [&]() {
+        if (w3early) {
+            const double *src = p.W3 + (long long)(v - 1) * wcnt0;
+#pragma unroll
+            for (int u = 0; u < kW3Pre; ++u) {
+                const int e = tid - kCompute + u * 64 * kLoaders;
+                w3pre[u] = src[e < wcnt0 ? e : 0];
+            }
+        }
+    };
+    const bool held = HM > 0 ? HELD : nl > 1;
+    if (!held) request_w3();
     // (the inputs are dead by now: their LDS holds the partial tiles of the matrix-core form)
     const int fchunks = p.fvec ? fvec_chunks(m, v, L.Z - L.A) : 0;
     double *sPart = lds + L.A;
@@ -923,12 +969,12 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         }
     }
     LSTAMP(11);
-    const bool held = HM > 0 ? HELD : nl > 1;
     const bool mfma_sums = p.H && held && 2 * m <= 16;
     // (a wavefront coming from the Gamma stores would take its item late and wait for the item's loads behind its
     // own stores: with Gamma requested the sums are the other wavefronts' alone)
     if (mfma_sums && (loader || !p.Gamma))
         held_sums_mfma(sG, sS, sQG, sQS, lds + L.Vcol, sTab, p.H + b * (long long)VM * VM, p.W3, sCnt, m, r, f, v, tid);
+    if (held) request_w3();
     LSTAMP(12);
     if (fchunks > 0) {
         lds_barrier();
@@ -943,7 +989,15 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
         if (loader) {  // block v-1 whole; the other slot starts as zeros (the loader then moves windows only)
             const double *src = p.W3 + (long long)(v - 1) * wcnt;
             double *dst = sW3 + ((v - 1) & 1) * wcnt, *oth = sW3 + (v & 1) * wcnt;
-            for (int e = tid - kCompute; e < wcnt; e += 64 * kLoaders) { dst[e] = src[e]; oth[e] = 0.0; }
+            if (w3early) {
+#pragma unroll
+                for (int u = 0; u < kW3Pre; ++u) {
+                    const int e = tid - kCompute + u * 64 * kLoaders;
+                    if (e < wcnt) { dst[e] = w3pre[u]; oth[e] = 0.0; }
+                }
+            } else {
+                for (int e = tid - kCompute; e < wcnt; e += 64 * kLoaders) { dst[e] = src[e]; oth[e] = 0.0; }
+            }
         }
         // The sweep runs on the Gram matrix Ht of plain-shift columns, Ht[a][b] = Ht[a+1][b+1] + G_(f-1-a)^T Q G_(f-1-b),
         // bordered by a virtual block row and column of index v: zero when f = v, and for f > v the short sums
