@@ -107,6 +107,62 @@ def test_workgroup_kernel_sparse_input_weight(ctx, n, m, r, f, v, pattern):
         assert_close(got, oracle_qp(orc, data, want=("H",))["H"], f"wg sparse W3 {pattern} n{n} m{m} r{r} f{f} v{v} H")
 
 
+@pytest.mark.parametrize("n,m,r,f,v", [
+    (10, 8, 2, 9, 9), (10, 8, 2, 12, 5),      # 2 m = 16: one shift per operand row of the held-input sums
+    (10, 3, 4, 14, 6), (9, 5, 2, 11, 4),      # 16 / m and 16 / (2 m) leave dead operand columns
+    (12, 9, 2, 7, 3), (18, 16, 2, 5, 2),      # 2 m > 16: held-input sums as dot products; fvec with one shift per row
+    (18, 17, 1, 4, 2), (18, 17, 2, 3, 3),     # m > 16: fvec as dot products as well
+    (8, 2, 3, 41, 17), (8, 2, 3, 41, 41),     # odd r: Gamma stored 8 bytes per lane
+    (8, 2, 2, 333, 40), (9, 1, 2, 520, 3),    # more than 16 operand-row groups of fvec, long held-input sums
+    (12, 4, 12, 50, 2), (12, 4, 12, 50, 49),  # shortest and longest swept part with held inputs
+])
+def test_workgroup_kernel_matrix_core_sums(ctx, n, m, r, f, v):
+    """fvec as a Hankel product, the held-input sums (both products of a tile in one wavefront) and their fall-backs,
+    over input counts that fill, under-fill and exceed the 16 columns of the matrix-core tile."""
+    rng = np.random.default_rng(31 * n + 17 * m + 13 * r + 7 * f + v)
+    batch = 5
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    data = dict(A=A, B=B, C=C, W3=rng.standard_normal((v * m, v * m)), Q=rng.standard_normal((r, r)),
+                x0=rng.standard_normal((batch, n)), ref=rng.standard_normal((batch, f * r)), f=f, v=v)
+    want = oracle_qp(orc, data)
+    got = _run(ctx, data, 1)
+    for k in ("Phi", "Gamma", "H", "fvec"):
+        assert_close(got[k], want[k], f"wg sums n{n} m{m} r{r} f{f} v{v} {k}")
+    only = _run(ctx, data, 1, want=("fvec",))
+    assert np.array_equal(only["fvec"], got["fvec"]), "fvec alone differs from the full call"
+    hf = _run(ctx, data, 1, want=("H", "fvec"))  # no Gamma: every wavefront takes held-input tiles
+    assert np.array_equal(hf["H"], got["H"]) and np.array_equal(hf["fvec"], got["fvec"])
+
+
+def test_workgroup_kernel_gamma_store_width(ctx):
+    """Gamma goes out 16 bytes per lane when the buffer is 16-byte aligned and 8 bytes per lane otherwise: the same
+    bits either way (device pointers, the second buffer one double further on)."""
+    import torch
+    from mpc_rs_amd import layout as L
+    n, m, r, f, v, batch = 8, 2, 2, 37, 21, 6
+    rng = np.random.default_rng(77)
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    dev = torch.device("cuda", 0)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bufs = [to(L.pack(x, 1)) for x in (A, B, C)]
+    w3, q = to(L.colmajor(rng.standard_normal((v * m, v * m)))), to(L.colmajor(rng.standard_normal((r, r))))
+    elems = f * r * v * m * batch
+    out = torch.zeros(2 * elems + 2, dtype=torch.float64, device=dev)
+    assert out.data_ptr() % 16 == 0
+    dims = ffi.make_dims(n, m, r, f, v, batch, 0, 1)
+    for off in (0, elems + 1):  # byte offsets 0 and 8 (mod 16)
+        ctx.qp_build_dev(dims, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), w3.data_ptr(), q.data_ptr(),
+                         None, None, None, out.data_ptr() + 8 * off, None, None, 0)
+    torch.cuda.synchronize()
+    g = out.cpu().numpy()
+    assert np.array_equal(g[:elems], g[elems + 1:2 * elems + 1])
+    data = dict(A=A, B=B, C=C, W3=np.zeros((v * m, v * m)), Q=np.eye(r), x0=np.zeros((batch, n)),
+                ref=np.zeros((batch, f * r)), f=f, v=v)
+    want = oracle_qp(orc, data)["Gamma"]
+    got = g[:elems].reshape(batch, v * m, f * r).transpose(0, 2, 1)
+    assert_close(got, want, "Gamma through device pointers")
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_workgroup_kernel_random_shapes(ctx, seed):
     """Seeded random shapes on the workgroup kernels: strides 1, 2 and 4 of the recurrences, held inputs (f > v),
