@@ -880,10 +880,18 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
                         dst2[pr] = pr < sp ? zero : x[u];
                     }
                 }
-                for (; p0 < FP; p0 += 64) {
-                    const int pr = p0 + lane;
-                    const v2d x = src2[pr < sp ? sp : (pr < FP ? pr : FP - 1)];
-                    if (pr < FP) dst2[pr] = pr < sp ? zero : x;
+                for (; p0 < FP; p0 += 64 * U2) {  // the rest of the column, again as one stretch (reads past the end clamped)
+                    v2d x[U2];
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        const int pr = p0 + 64 * u + lane;
+                        x[u] = src2[pr < sp ? sp : (pr < FP ? pr : FP - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U2; ++u) {
+                        const int pr = p0 + 64 * u + lane;
+                        if (pr < FP) dst2[pr] = pr < sp ? zero : x[u];
+                    }
                 }
                 continue;
             }
