@@ -1,5 +1,6 @@
 """Phase stamps of the workgroup QP kernel (needs a library built with -DMPCX_WG_STAMPS, e.g. tools/build_variant.sh stamps qp_wg.hip -DMPCX_WG_STAMPS, and MPCX_LIB pointing at it; diagnostic, GPU only).
-With STAMPS2=1 in the environment and a -DMPCX_WG_STAMPS2 build: fvec is computed and the first loader wave's stamps around fvec and the held-input sums are printed (pass an output list without Phi: the stamps live in its buffer)."""
+With STAMPS2=1 in the environment and a -DMPCX_WG_STAMPS2 build: fvec is computed and the first loader wave's stamps around fvec and the held-input sums are printed (pass an output list without Phi: the stamps live in its buffer).
+With PER_XCD=1: mean start, end and duration of the workgroups of each XCD (workgroup i runs on XCD i % 8)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,3 +39,9 @@ for half in (0, 1):
     sel = dt[mid][half::2]
     print(("even" if half == 0 else "odd ") + " blocks: " + "  ".join(f"{nm} {x:6.1f}" for nm, x in zip(names, sel.mean(axis=0))) + f"  total {(st[mid][half::2, 9] - st[mid][half::2, 0]).mean() / 100:.1f} us")
 print("kernel span %.3f ms" % ((st[:, 9].max() - st[:, 0].min()) / 1e5))
+if os.environ.get("PER_XCD"):  # workgroup i runs on XCD i % 8: mean start, end and duration per XCD and dispatch round
+    t0 = st[:, 0].min()
+    for x in range(8):
+        sel = st[x::8]
+        print(f"XCD {x}: start {(sel[:, 0] - t0).mean() / 100:7.1f}  end {(sel[:, 9] - t0).mean() / 100:7.1f}  duration {(sel[:, 9] - sel[:, 0]).mean() / 100:6.1f} us;"
+              f" first 512: {(sel[:64, 9] - sel[:64, 0]).mean() / 100:6.1f}, rest: {(sel[64:, 9] - sel[64:, 0]).mean() / 100:6.1f}")
