@@ -934,7 +934,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     // The first column block of W3 the sweep needs (block v-1) is requested ahead of time by the loader waves and
     // written to its ring slot when the sweep's buffers become free: its latency passes behind fvec (without held
     // inputs) or behind the wait for the other wavefronts (with them: requested after the sums, which need the registers).
-    constexpr int kW3Pre = 8;
+    constexpr int kW3Pre = HM > 0 ? 8 : 2;  // (the generic kernel has no registers to spare for more)
     const int wcnt0 = VM * m;
     const bool w3early = p.H && loader && wcnt0 <= kW3Pre * 64 * kLoaders;
     double w3pre[kW3Pre];
