@@ -415,11 +415,18 @@ def main():
             try:
                 c = make_case(wl_name, op, f_over=fo, v_over=vo)
                 c.step()
+                torch.cuda.synchronize()
+                t_w = time.perf_counter()
                 c.step()
+                torch.cuda.synchronize()
+                # short kernels speed up over the first launches of a process: about 20 ms of them before the clock starts
+                n_warm = 2 + min(8, int(0.02 / max(time.perf_counter() - t_w, 1e-5)))
+                for _ in range(n_warm - 2):
+                    c.step()
                 torch.cuda.synchronize()
                 ms = event_ms(c.step, args.also_steps)
                 ach = c.unit_bytes * c.per_gpu / (ms * 1e-3)
-                also.append({"workload": c.name, "op": op, "batch": c.per_gpu, "interleave": c.il, "steps": args.also_steps,
+                also.append({"workload": c.name, "op": op, "batch": c.per_gpu, "interleave": c.il, "steps": args.also_steps, "warmup": n_warm,
                              "ms_per_step": ms, "value": c.per_gpu / (ms * 1e-3), "unit": c.unit,
                              "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                           "frac": ach / HBM_PEAK, "traffic": _traffic(op, wl_name, c.per_gpu, c.f, c.v),
