@@ -3,7 +3,8 @@
 //   mode 1  the same with eight LDS reads (8 bytes per lane, constant offsets) feeding every four products
 //   mode 2  mode 1 while three more wavefronts per SIMD run dependent FP64 multiply-adds
 //   mode 3  mode 1 while three more wavefronts per SIMD stream LDS reads
-// One workgroup per CU (256 + 768 threads), time per product of the MFMA wavefronts printed in ns and cycles at 2.4 GHz.
+// One workgroup per CU (256 + 768 threads), time per product of the MFMA wavefronts printed in ns and cycles at 2.4 GHz;
+// then modes 0 and 1 with two and four MFMA wavefronts per SIMD.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_f64_rate.hip -o tools/mfma_f64_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -11,13 +12,13 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(1024) void probe(double *out, int rounds, int mode) {
+__global__ __launch_bounds__(1024) void probe(double *out, int rounds, int mode, int mfma_waves) {
     __shared__ double buf[8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 8192; i += blockDim.x) buf[i] = 1.0 + 1e-9 * i;
     __syncthreads();
     double res = 0.0;
-    if (wave < 4) {  // one MFMA wavefront per SIMD (waves are dealt round-robin to the four SIMDs)
+    if (wave < mfma_waves) {  // mfma_waves / 4 MFMA wavefronts per SIMD (waves are dealt round-robin to the four SIMDs)
         d4 a0 = {0, 0, 0, 0}, a1 = a0, b0 = a0, b1 = a0;
         double x = 1.0 + lane * 1e-6, y = 1.0 - lane * 1e-6;
         const double *pa = buf + (lane & 15) * 24 + (lane >> 4), *pb = buf + 4096 + (lane & 15) * 12 + (lane >> 4);
@@ -59,11 +60,19 @@ int main() {
     for (int mode = 0; mode < 4; ++mode)
         for (int threads : {256, 1024}) {
             if (mode < 2 && threads == 1024 && mode == 0) {}
-            probe<<<256, threads>>>(out, rounds, mode); CK(hipDeviceSynchronize());
-            CK(hipEventRecord(a)); probe<<<256, threads>>>(out, rounds, mode); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            probe<<<256, threads>>>(out, rounds, mode, 4); CK(hipDeviceSynchronize());
+            CK(hipEventRecord(a)); probe<<<256, threads>>>(out, rounds, mode, 4); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
             float ms; CK(hipEventElapsedTime(&ms, a, b));
             const double ns = ms * 1e6 / (rounds * 4.0);
             printf("mode %d threads %4d : %7.1f ns per product of a wavefront = %6.1f cycles at 2.4 GHz\n", mode, threads, ns, ns * 2.4);
+        }
+    for (int mode = 0; mode < 2; ++mode)
+        for (int mw : {8, 16}) {  // two and four MFMA wavefronts per SIMD: time per product of ONE wavefront; the SIMD's is that / (mw / 4)
+            probe<<<256, 64 * mw>>>(out, rounds, mode, mw); CK(hipDeviceSynchronize());
+            CK(hipEventRecord(a)); probe<<<256, 64 * mw>>>(out, rounds, mode, mw); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            const double ns = ms * 1e6 / (rounds * 4.0);
+            printf("mode %d, %d MFMA wavefronts per SIMD : %7.1f ns per product of a wavefront, %6.1f ns per product of the SIMD\n", mode, mw / 4, ns, ns / (mw / 4));
         }
     return 0;
 }
