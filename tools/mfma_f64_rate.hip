@@ -11,6 +11,9 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
 typedef double d4 __attribute__((ext_vector_type(4)));
+#ifndef ROWSTRIDE
+#define ROWSTRIDE 24  // doubles between the operand rows of neighbouring lanes (24: as in qp_wg for r = 12; 4-way bank conflicts)
+#endif
 
 __global__ __launch_bounds__(1024) void probe(double *out, int rounds, int mode, int mfma_waves) {
     __shared__ double buf[8192];
@@ -21,7 +24,7 @@ __global__ __launch_bounds__(1024) void probe(double *out, int rounds, int mode,
     if (wave < mfma_waves) {  // mfma_waves / 4 MFMA wavefronts per SIMD (waves are dealt round-robin to the four SIMDs)
         d4 a0 = {0, 0, 0, 0}, a1 = a0, b0 = a0, b1 = a0;
         double x = 1.0 + lane * 1e-6, y = 1.0 - lane * 1e-6;
-        const double *pa = buf + (lane & 15) * 24 + (lane >> 4), *pb = buf + 4096 + (lane & 15) * 12 + (lane >> 4);
+        const double *pa = buf + (lane & 15) * ROWSTRIDE + (lane >> 4), *pb = buf + 4096 + (lane & 15) * (ROWSTRIDE / 2) + (lane >> 4);
         for (int r = 0; r < rounds; ++r) {
             if (mode == 0) {
                 a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
