@@ -22,6 +22,7 @@ struct QpArgs {
     // two ints of device scratch in which the workgroup kernels measure the band structure of W3, or null
     void *w3win;
     size_t w3win_bytes;
+    int cu_count;  // compute units of the device (filled in by the workgroup kernels' launcher; 0: unknown)
 };
 
 struct RolloutArgs {

@@ -843,7 +843,12 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     //      last, so that one workgroup's store stream overlaps the other's sweep.
     //      Only where Gamma is at least as large as H (f r >= v m), and not with held inputs (f > v): there the
     //      other wavefronts form fvec and the held-input sums while Gamma is stored, which hides both. ----
-    const bool gamma_last = p.Gamma && p.H && FR >= VM && (blockIdx.x & 1) && !(f > v);
+    //      With held inputs the alternation is on only for a batch of at most two rounds of resident workgroups: those
+    //      run in lockstep (all store Gamma at once, all sweep at once), and what alternates is then the CU slot
+    //      (workgroups i and i + #CU share a CU in the first round; i and i + 1 sit on different XCDs).
+    const bool lockstep = p.cu_count > 0 && gridDim.x <= 4u * (unsigned)p.cu_count;
+    const bool gamma_last = p.Gamma && p.H && FR >= VM &&
+                            ((f > v) ? (lockstep && ((blockIdx.x / (unsigned)p.cu_count) & 1)) : (blockIdx.x & 1));
     auto write_gamma = [&]() {
         // A wavefront takes a column at a time, lanes along its rows.  The LDS reads of a stretch of rows all issue
         // before the first store (one LDS round trip per stretch, not per store instruction); rows above the block
@@ -980,7 +985,7 @@ __global__ __launch_bounds__(kWgBlock, 4) void qp_wg_kernel(QpArgs p) {
     const bool mfma_sums = p.H && held && 2 * m <= 16;
     // (a wavefront coming from the Gamma stores would take its item late and wait for the item's loads behind its
     // own stores: with Gamma requested the sums are the other wavefronts' alone)
-    if (mfma_sums && (loader || !p.Gamma))
+    if (mfma_sums && (loader || !p.Gamma || gamma_last))
         held_sums_mfma(sG, sS, sQG, sQS, lds + L.Vcol, sTab, p.H + b * (long long)VM * VM, p.W3, sCnt, m, r, f, v, tid);
     if (held) request_w3();
     LSTAMP(12);
@@ -1192,6 +1197,18 @@ int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s) {
     if (a.batch > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     // reach of W3's non-zeros around the block diagonal, for the sweep's loader waves (only where they move 16-byte pairs)
     QpArgs b = a;
+    b.cu_count = 0;
+    {
+        static int cus[64];  // per device, filled on first use (0: not asked yet)
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (cus[dev] == 0) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus[dev] = n;
+            }
+            b.cu_count = cus[dev];
+        }
+    }
     const long long wcnt = (long long)a.v * a.m * a.m;
     if (a.H && a.W3 && a.w3win && (wcnt & 1) == 0 && ((uintptr_t)a.W3 & 15) == 0 && a.w3win_bytes >= 2 * sizeof(int)) {
         hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.w3win, INT_MIN, 2, s);
