@@ -1,8 +1,9 @@
 # Round-2 evidence: per-kernel time (rocprofv3 --kernel-trace --stats) and HBM traffic (one --pmc WRITE_SIZE and one
-# --pmc FETCH_SIZE pass) of the benched kernels.  Usage (GPU box): bash tools/profile_r02.sh [kt|pmc|all]
+# --pmc FETCH_SIZE pass) of the benched kernels.  Usage (GPU box): bash tools/profile_r02.sh [kt|pmc|all] [one case name]
 # Afterwards, here: python tools/summarize_r02.py
 set -e
 what=${1:-all}
+only=${2:-}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02
@@ -23,6 +24,7 @@ cases=(
 )
 for c in "${cases[@]}"; do
   name=${c%%|*}; args=${c#*|}
+  if [ -n "$only" ] && [ "$only" != "$name" ]; then continue; fi
   if [ "$what" != "pmc" ]; then
     timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$name -o $name -- python3 $R/bench.py $B $args > $O/kt_$name.json 2> $O/kt_$name.err
     echo "kt $name done"
