@@ -14,7 +14,7 @@ cases=(
  "qp_msd|--workload msd"
  "qp_quadrotor|--workload quadrotor --steps 5 --warmup 1"
  "qp_long|--workload long --steps 5 --warmup 1"
- "qp_quadrotor_held|--workload quadrotor --f 50 --v 25 --steps 5 --warmup 1"
+ "qp_quadrotor_held|--workload quadrotor --f 50 --v 25 --steps 12 --warmup 4"
  "qp_long_held|--workload long --f 400 --v 200 --steps 5 --warmup 1"
  "rollout_msd|--workload msd --op rollout --steps 5 --warmup 1"
  "rollout_two_mass|--workload two_mass --op rollout --steps 5 --warmup 1"
