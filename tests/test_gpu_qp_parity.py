@@ -134,6 +134,20 @@ def test_workgroup_kernel_matrix_core_sums(ctx, n, m, r, f, v):
     assert np.array_equal(hf["H"], got["H"]) and np.array_equal(hf["fvec"], got["fvec"])
 
 
+@pytest.mark.parametrize("n,m,r,f,v,batch", [(8, 2, 2, 30, 7, 600), (12, 4, 12, 9, 4, 520), (10, 3, 4, 14, 6, 700)])
+def test_workgroup_kernel_held_inputs_second_workgroup_per_cu(ctx, n, m, r, f, v, batch):
+    """Held inputs with more instances than compute units but at most four per CU: the workgroups of the second CU
+    slot sweep first and write Gamma last (and take part in the held-input sums); every instance against the oracle."""
+    rng = np.random.default_rng(n + 3 * m + 5 * r + 7 * f + 11 * v + batch)
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    data = dict(A=A, B=B, C=C, W3=rng.standard_normal((v * m, v * m)), Q=rng.standard_normal((r, r)),
+                x0=rng.standard_normal((batch, n)), ref=rng.standard_normal((batch, f * r)), f=f, v=v)
+    want = oracle_qp(orc, data)
+    got = _run(ctx, data, 1)
+    for k in ("Phi", "Gamma", "H", "fvec"):
+        assert_close(got[k], want[k], f"wg held, two slots n{n} m{m} r{r} f{f} v{v} {k}")
+
+
 def test_workgroup_kernel_gamma_store_width(ctx):
     """Gamma goes out 16 bytes per lane when the buffer is 16-byte aligned and 8 bytes per lane otherwise: the same
     bits either way (device pointers, the second buffer one double further on)."""
