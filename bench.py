@@ -157,6 +157,7 @@ def main():
             return torch.empty(L.array_elems(count, il, elems), dtype=torch.float64, device=dev)
 
         info = None
+        h_only = None
         if op == "qp":
             outs = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
             dims = ffi.make_dims(n, m, r, f, v, count, 0, il, ffi.WEIGHTS_BLOCK, hessian)
@@ -166,6 +167,10 @@ def main():
                                  bufs["W3"].data_ptr(), bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(),
                                  outs["Phi"].data_ptr(), outs["Gamma"].data_ptr(), outs["H"].data_ptr(),
                                  outs["fvec"].data_ptr(), sp)
+            def h_only():  # the Hessian alone (with hessian_algo = CONTRACT: the matrix-core kernel on its own)
+                ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(),
+                                 bufs["W3"].data_ptr(), bufs["Q"].data_ptr(), None, None, None, None, outs["H"].data_ptr(),
+                                 None, sp)
             unit_bytes = bytes_qp(n, m, r, f, v)
             metric, unit = "batched MPC QP builds/sec (Phi,Gamma,H,f)", "builds/s"
             check_buf = outs["H"]
@@ -242,7 +247,7 @@ def main():
         name = f"{workload}: n={n} m={m} r={r} " + (f"f=v={f}" if f == v else f"f={f} v={v}") + (f" T={T}" if op in ("rollout", "loop") else "")
         return SimpleNamespace(workload=workload, op=op, name=name, n=n, m=m, r=r, f=f, v=v, T=T, il=il, per_gpu=per_gpu,
                                count=count, d=d, bufs=bufs, outs=outs, dims=dims, step=step, unit_bytes=unit_bytes,
-                               metric=metric, unit=unit, check_buf=check_buf, info=info, hessian=hessian)
+                               metric=metric, unit=unit, check_buf=check_buf, info=info, hessian=hessian, h_only=h_only)
 
     def event_ms(fn, steps):
         """Mean duration of fn() over `steps` calls, HIP events on the launch stream around each call."""
@@ -280,13 +285,9 @@ def main():
     # ---- hessian_algo = CONTRACT: the dominant kernel is the FP64-MFMA contraction; time it on its own ----
     mfma_ms = None
     if args.op == "qp" and args.hessian == 1:
-        def h_only():
-            ctx.qp_build_dev(dims, bufs["A"].data_ptr(), bufs["B"].data_ptr(), bufs["C"].data_ptr(),
-                             bufs["W3"].data_ptr(), bufs["Q"].data_ptr(), None, None, None, None, outs["H"].data_ptr(),
-                             None, sp)
-        h_only()
+        case.h_only()
         torch.cuda.synchronize()
-        mfma_ms = event_ms(h_only, args.steps)
+        mfma_ms = event_ms(case.h_only, args.steps)
 
     # ---- statistics record of this shard; ranks exchange records (RCCL), never results ----
     rec = torch.zeros(6, dtype=torch.int64, device=dev)
@@ -381,39 +382,26 @@ def main():
         if lib_gather is not None:
             res["lib_gather"] = lib_gather
         if mfma_ms is not None:
-            # The contraction kernel against the FP64 matrix-core peak.  `frac` counts the flops the kernel EXECUTES:
-            # one v_mfma_f64_16x16x4_f64 is 2048 flops and the kernel issues a number of them that depends on the shape
-            # only (_mfma_insts, checked against the SQ_INSTS_VALU_MFMA_F64 counter pass recorded under profiles/).
-            # The algorithmic rate (symmetric count, block-diagonal weight) is a side field: it exceeds what ran only
-            # on paper, because the dense contraction also multiplies structural zeros.
-            symmetric = bool(np.array_equal(case.d["W3"], case.d["W3"].T) and np.array_equal(case.d["Q"], case.d["Q"].T))
-            insts = _mfma_insts(m, r, f, v, per_gpu, symmetric)
-            fl_alg = flops_h(m, r, f, v) * per_gpu / (mfma_ms * 1e-3)
-            fl_exec = (insts * 2048.0 / (mfma_ms * 1e-3)) if insts else None
-            res["roofline"] = {"bound": "mfma", "achieved": (fl_exec or 0.0) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
-                               "frac": (fl_exec / FP64_PEAK) if fl_exec else None, "traffic": None, "kernel_ms": mfma_ms,
-                               "kernel": "hessian_mfma_kernel", "mfma_insts_per_launch": insts, "symmetric_tiles_skipped": symmetric,
-                               "algorithmic_TFLOP_per_s": fl_alg / 1e12, "algorithmic_frac": fl_alg / FP64_PEAK,
-                               "flops_per_unit": flops_h(m, r, f, v),
-                               "dense_flops_per_unit": 2 * f * r * (v * m) ** 2, "step_ms_all_kernels": kernel_ms,
-                               "hbm_frac_whole_step": achieved / HBM_PEAK}
+            res["roofline"] = _mfma_roofline(case, mfma_ms, kernel_ms, achieved)
         if args.op in ("solve", "gain", "loop", "plants"):
             res["check"]["singular_instances"] = int((case.info != 0).sum().item())
         if world == 1 and not args.no_cpu_baseline and args.op in ("qp", "rollout"):
             res["cpu_baseline"] = _cpu_baseline(args, case.d, n, m, r, f, v, T, case.unit, outs, il, count)
 
     # ---- the other configurations, N = 1 and the default command only: same timing, a few steps each ----
+    also_failed = []
     if world == 1 and not args.no_also and args.workload == "two_mass" and args.op == "qp" and not (args.f or args.batch or args.hessian):
         del case, outs, bufs, check_buf
         torch.cuda.empty_cache()
         also = []
         t_also = time.perf_counter()
-        for wl_name, op, fo, vo in ALSO:
-            if time.perf_counter() - t_also > 60.0:  # never let the extras dominate the run
+        for wl_name, op, fo, vo, hess in ALSO:
+            if time.perf_counter() - t_also > ALSO_BUDGET_S:  # a regression, not a detail: reported and the run fails
                 also.append({"workload": wl_name, "op": op, "skipped": "time budget"})
+                also_failed.append(f"{wl_name}:{op}: not run, the extra configurations exceeded {ALSO_BUDGET_S:.0f} s")
                 continue
             try:
-                c = make_case(wl_name, op, f_over=fo, v_over=vo)
+                c = make_case(wl_name, op, f_over=fo, v_over=vo, hessian=hess)
                 c.step()
                 torch.cuda.synchronize()
                 t_w = time.perf_counter()
@@ -429,28 +417,61 @@ def main():
                 torch.cuda.synchronize()
                 ms = event_ms(c.step, args.also_steps)
                 ach = c.unit_bytes * c.per_gpu / (ms * 1e-3)
-                also.append({"workload": c.name, "op": op, "batch": c.per_gpu, "interleave": c.il, "steps": args.also_steps, "warmup": n_warm,
-                             "ms_per_step": ms, "value": c.per_gpu / (ms * 1e-3), "unit": c.unit,
-                             "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                          "frac": ach / HBM_PEAK, "traffic": _traffic(op, wl_name, c.per_gpu, c.f, c.v),
-                                          "bytes_per_unit": c.unit_bytes}})
+                rec = {"workload": c.name, "op": op, "batch": c.per_gpu, "interleave": c.il, "steps": args.also_steps, "warmup": n_warm,
+                       "ms_per_step": ms, "value": c.per_gpu / (ms * 1e-3), "unit": c.unit,
+                       "roofline": {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                    "frac": ach / HBM_PEAK, "traffic": _traffic(op, wl_name, c.per_gpu, c.f, c.v),
+                                    "bytes_per_unit": c.unit_bytes}}
+                if hess == 1:  # the matrix-core contraction on its own, against the FP64 MFMA peak
+                    c.h_only()
+                    torch.cuda.synchronize()
+                    rec["hessian_algo"] = 1
+                    rec["roofline"] = _mfma_roofline(c, event_ms(c.h_only, args.also_steps), ms, ach)
+                if c.info is not None:
+                    rec["singular_instances"] = int((c.info != 0).sum().item())
+                also.append(rec)
                 del c
                 torch.cuda.empty_cache()
-            except Exception as exc:  # an extra must never cost the headline line
+            except Exception as exc:  # reported in the line, and the run fails after printing it
                 also.append({"workload": wl_name, "op": op, "error": str(exc)[:200]})
+                also_failed.append(f"{wl_name}:{op}: {str(exc)[:200]}")
         res["also"] = also
     if rank == 0:
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    if also_failed:  # the line above is complete; an extra configuration that failed or was not run is still a failure
+        sys.exit("bench.py: " + "; ".join(also_failed))
 
 
-# extra configurations of the default run: (workload, op, f override, v override)
-ALSO = (("msd", "qp", 0, 0), ("quadrotor", "qp", 0, 0), ("long", "qp", 0, 0),
-        ("quadrotor", "qp", 50, 25), ("long", "qp", 400, 200),
-        ("msd", "rollout", 0, 0), ("two_mass", "rollout", 0, 0), ("quadrotor", "rollout", 0, 0),
-        ("two_mass", "gain", 0, 0), ("two_mass", "loop", 0, 0), ("quadrotor", "gain", 0, 0), ("long", "gain", 0, 0))
+# extra configurations of the default run: (workload, op, f override, v override, hessian_algo)
+ALSO = (("msd", "qp", 0, 0, 0), ("quadrotor", "qp", 0, 0, 0), ("long", "qp", 0, 0, 0),
+        ("quadrotor", "qp", 50, 25, 0), ("long", "qp", 400, 200, 0),
+        ("two_mass", "qp", 32, 32, 0), ("two_mass", "qp", 30, 10, 0),   # run-time horizons on the one-lane kernel
+        ("long", "qp", 0, 0, 1),                                        # H as the FP64 matrix-core contraction
+        ("msd", "rollout", 0, 0, 0), ("two_mass", "rollout", 0, 0, 0), ("quadrotor", "rollout", 0, 0, 0),
+        ("two_mass", "solve", 0, 0, 0), ("two_mass", "gain", 0, 0, 0), ("two_mass", "loop", 0, 0, 0),
+        ("quadrotor", "loop", 0, 0, 0), ("quadrotor", "gain", 0, 0, 0), ("long", "gain", 0, 0, 0))
+ALSO_BUDGET_S = 120.0  # the extras take about 25 s; beyond this something has regressed and the run fails
+
+def _mfma_roofline(case, mfma_ms, step_ms, achieved_bytes_per_s):
+    """The contraction kernel against the FP64 matrix-core peak.  `frac` counts the flops the kernel EXECUTES: one
+    v_mfma_f64_16x16x4_f64 is 2048 flops and the kernel issues a number of them that depends on the shape only
+    (_mfma_insts, checked against the SQ_INSTS_VALU_MFMA_F64 counter pass recorded under profiles/).  The algorithmic
+    rate (symmetric count, block-diagonal weight) is a side field: it exceeds what ran only on paper, because the dense
+    contraction also multiplies structural zeros."""
+    m, r, f, v, per_gpu = case.m, case.r, case.f, case.v, case.per_gpu
+    symmetric = bool(np.array_equal(case.d["W3"], case.d["W3"].T) and np.array_equal(case.d["Q"], case.d["Q"].T))
+    insts = _mfma_insts(m, r, f, v, per_gpu, symmetric)
+    fl_alg = flops_h(m, r, f, v) * per_gpu / (mfma_ms * 1e-3)
+    fl_exec = (insts * 2048.0 / (mfma_ms * 1e-3)) if insts else None
+    return {"bound": "mfma", "achieved": (fl_exec or 0.0) / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": (fl_exec / FP64_PEAK) if fl_exec else None, "traffic": None, "kernel_ms": mfma_ms,
+            "kernel": "hessian_mfma_kernel", "mfma_insts_per_launch": insts, "symmetric_tiles_skipped": symmetric,
+            "algorithmic_TFLOP_per_s": fl_alg / 1e12, "algorithmic_frac": fl_alg / FP64_PEAK,
+            "flops_per_unit": flops_h(m, r, f, v), "dense_flops_per_unit": 2 * f * r * (v * m) ** 2,
+            "step_ms_all_kernels": step_ms, "hbm_frac_whole_step": achieved_bytes_per_s / HBM_PEAK}
 
 
 def _mfma_insts(m, r, f, v, per_gpu, symmetric=False):

@@ -153,12 +153,12 @@ int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, 
                          const double *x0, const double *U, double *X, double *Y, void *stream);
 
 /*
- * Batched solve with the condensed Hessian: Gaussian elimination with partial pivoting per instance.  nalgebra's
- * try_inverse does the same for dimensions above 4 and takes closed-form (cofactor) inverses for 1..4, which fail on
- * `determinant == 0.0` (controller.rs:93-95, model.rs:56); the device always pivots.  For v m <= 4 (and n <= 4 in the
- * discretisation) the two therefore agree on exactly singular matrices built from exact zeros, may flag different
- * instances among matrices that are singular only to rounding, and round differently on the rest (within the 1e-10
- * bar scaled by the condition number).
+ * Batched solve with the condensed Hessian, following nalgebra's try_inverse (controller.rs:93-95, model.rs:56) in both
+ * of its regimes.  Systems of 1..4 unknowns (v m <= 4; n <= 4 in the discretisation): the same closed-form (cofactor)
+ * inverses, evaluated with multiply and add kept separate, failing exactly where try_inverse returns None, on
+ * `determinant == 0.0`; the one deviation is that a non-finite determinant is flagged as well.  Above 4 unknowns:
+ * Gaussian elimination with partial pivoting per instance, as nalgebra's LU; an exactly zero or non-finite pivot fails.
+ * Results agree with the reference's to the 1e-10 bar scaled by the condition number.
  *   mpcx_qp_solve:  u_seq (v m per instance) = -H^-1 fvec: the optimal input sequence; its first m entries are the
  *                   move the reference applies (controller.rs:130-134 with gain s = -H^-1 fvec).
  *   mpcx_qp_gain:   gain ((v m) x (f r) per instance) = H^-1 Gamma^T W4, the reference's gain_matrix

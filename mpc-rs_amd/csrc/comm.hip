@@ -147,21 +147,32 @@ int mpcx_comm_create(mpcx_comm **out, mpcx_ctx *ctx, const void *id, int world, 
     c->world = world;
     c->rank = rank;
     c->err[0] = 0;
+    c->stream = nullptr;
+    c->ready = nullptr;
+    c->recs_dev = nullptr;
+    // every failure below releases what was created before it and leaves its text for mpcx_comm_last_error(NULL)
+    auto release = [&]() {
+        if (c->recs_dev) (void)hipFree(c->recs_dev);
+        if (c->ready) (void)hipEventDestroy(c->ready);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+    };
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&c->recs_dev, sizeof(mpcx_stats) * (size_t)(world + 1));
     if (e != hipSuccess) {
-        delete c;
+        snprintf(g_rccl_error, sizeof(g_rccl_error), "mpcx_comm_create on device %d: %s", c->device, hipGetErrorString(e));
+        release();
         return (int)e;
     }
     ncclUniqueId uid;
     memcpy(uid.internal, id, MPCX_COMM_ID_BYTES);
-    if (api->CommInitRank(&c->comm, world, uid, rank) != ncclSuccess) {
-        (void)hipFree(c->recs_dev);
-        (void)hipEventDestroy(c->ready);
-        (void)hipStreamDestroy(c->stream);
-        delete c;
+    const ncclResult_t nr = api->CommInitRank(&c->comm, world, uid, rank);
+    if (nr != ncclSuccess) {
+        snprintf(g_rccl_error, sizeof(g_rccl_error), "ncclCommInitRank (rank %d of %d, device %d): %s", rank, world, c->device,
+                 api->GetErrorString(nr));
+        release();
         return MPCX_ERR_COMM;
     }
     *out = c;

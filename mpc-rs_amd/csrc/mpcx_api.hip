@@ -352,7 +352,12 @@ int mpcx_reserve(mpcx_ctx *ctx, const mpcx_dims *d) {
     if (W != 1 && (!qp_lane_takes(a) || d->hessian_algo == MPCX_HESSIAN_CONTRACT)) {  // instance-major copy of a build
         const long long n = d->n, m = d->m, r = d->r, FR = (long long)d->f * r, VM = (long long)d->v * m;
         const long long per = n * n + n * m + r * n + n + FR + FR * n + FR * VM + VM * VM + VM;
-        if ((rc = ensure_relay(ctx, (size_t)relay_chunk(ctx, per, d->batch) * (size_t)per * sizeof(double))) != MPCX_OK) return rc;
+        // A later build may ask for fewer outputs: its per-instance size is smaller, its chunk holds more instances and
+        // chunk x size can exceed what the all-outputs chunk takes (both stay under the cap, or one instance where one
+        // instance exceeds the cap).  Reserve the bound that covers every subset: min(max(cap, one instance), whole batch).
+        const size_t one = (size_t)per * sizeof(double), whole = one * (size_t)d->batch;
+        const size_t bound = ctx->relay_cap > one ? ctx->relay_cap : one;
+        if ((rc = ensure_relay(ctx, bound < whole ? bound : whole)) != MPCX_OK) return rc;
     }
     return MPCX_OK;
 }

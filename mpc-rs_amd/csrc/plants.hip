@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void c2d_m_kernel(const double *Acp, double dt
     const int j = (int)(e / n), i = (int)(e - (long long)j * n);
     const long long at = elem_index(b, e, E, W);
     const double id = (i == j) ? 1.0 : 0.0;
-    Mt[at] = id - Acp[at] * dt;
+    Mt[at] = one_minus_scaled(id, Acp[at], dt);  // product rounded before the subtraction: the closed forms test det == 0.0
     Ap[at] = id;
 }
 

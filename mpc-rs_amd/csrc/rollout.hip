@@ -92,6 +92,9 @@ int launch_lane_one(const RolloutArgs &a, hipStream_t s) {
 #define MPCX_RO_CHUNK 8
 #endif
 constexpr int kChunk = MPCX_RO_CHUNK;
+// The line-aligned flush of the instance-major outputs relies on a full chunk advancing a row by a whole number of
+// 128-byte lines: kChunk * rows doubles with even rows, i.e. kChunk a multiple of 8.
+static_assert(kChunk % 8 == 0, "MPCX_RO_CHUNK must be a multiple of 8 (whole 128-byte lines per chunk for even row counts)");
 
 // LDS doubles per instance, kept even (16-byte aligned pairs).  (Staggering the instances of a wavefront over the LDS
 // banks by padding was measured: no gain, and the extra bytes cost resident wavefronts.)

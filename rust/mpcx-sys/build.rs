@@ -4,9 +4,10 @@ use std::env;
 use std::path::PathBuf;
 use std::process::Command;
 
-const SOURCES: [&str; 11] = [
+// the SRCS list of mpc-rs_amd/csrc/Makefile, in its order (tests/test_host_cpu.py holds the two against each other)
+const SOURCES: [&str; 12] = [
     "mpcx_api.hip", "qp_lane.hip", "qp_wg.hip", "hessian_mfma.hip", "dense_w4.hip", "solve.hip", "solve_large.hip",
-    "plants.hip", "closed_loop.hip", "rollout.hip", "util.hip",
+    "plants.hip", "closed_loop.hip", "rollout.hip", "util.hip", "comm.hip",
 ];
 
 fn main() {
@@ -34,6 +35,7 @@ fn main() {
     }
     println!("cargo:rerun-if-changed={}", include.join("mpcx.h").display());
     cmd.arg("-o").arg(out.join("libmpcx.so"));
+    cmd.arg("-ldl"); // comm.hip binds RCCL with dlopen at the first communicator call
     let status = cmd.status().expect("hipcc could not be started (set HIPCC, or MPCX_LIB_DIR to a prebuilt libmpcx.so)");
     assert!(status.success(), "hipcc failed to build libmpcx.so");
     println!("cargo:rustc-link-search=native={}", out.display());

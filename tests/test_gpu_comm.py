@@ -21,7 +21,21 @@ def test_plain_c_one_rank_communicator():
         subprocess.run(["make", "-C", os.path.join(HERE, "c_abi")], check=True, capture_output=True)
     p = subprocess.run([EXE], capture_output=True, text=True, timeout=180)
     assert p.returncode == 0, (p.stdout, p.stderr)
-    assert "comm ok count=100003" in p.stdout and "bad_root rc=-2" in p.stdout
+    assert "comm ok world=1 rank=0 count=100003" in p.stdout and "bad_root rc=-2" in p.stdout
+
+
+def test_plain_c_rank_of_a_world_through_an_id_file(tmp_path):
+    """The multi-process form of the same program (`comm_check WORLD RANK ID_FILE`, one process per GPU on a node) with
+    the only world a one-GPU box can form: rank 0 publishes the communicator id as a file, exactly as it does for 8."""
+    if not os.path.exists(EXE):
+        subprocess.run(["make", "-C", os.path.join(HERE, "c_abi")], check=True, capture_output=True)
+    idf = tmp_path / "mpcx.id"
+    p = subprocess.run([EXE, "1", "0", str(idf), "0"], capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, (p.stdout, p.stderr)
+    assert idf.stat().st_size == ffi.COMM_ID_BYTES
+    assert "comm ok world=1 rank=0 count=100003" in p.stdout
+    bad = subprocess.run([EXE, "2", "2", str(idf)], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "usage" in bad.stdout
 
 
 def test_one_rank_communicator_in_process(ctx):

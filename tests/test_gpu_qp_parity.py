@@ -49,6 +49,33 @@ def test_lane_kernel_shapes_and_held_input(ctx, n, m, r, f, v):
             assert_close(got[k], want[k], f"n{n} m{m} r{r} f{f} v{v} W={il} {k}")
 
 
+@pytest.mark.parametrize("n,m,r", [(5, 2, 2), (3, 2, 2), (2, 3, 1), (6, 1, 3), (1, 2, 2), (5, 1, 2), (2, 1, 2), (6, 3, 3),
+                                   (1, 3, 3), (4, 3, 2)])
+@pytest.mark.parametrize("f,v", [(20, 20), (9, 4), (5, 1)])
+def test_small_plants_outside_the_exact_lane_shapes(ctx, n, m, r, f, v):
+    """Plants of at most 6 states and 3 inputs / outputs whose (n, m, r) is not one of the exactly instantiated one-lane
+    shapes: block weights as Controller::new builds them (controller.rs:149-185, all-elements blocks and q I blocks),
+    every batch layout, ragged batch."""
+    rng = np.random.default_rng(3000 + 100 * n + 10 * m + r + f + v)
+    batch = 200
+    A, B, C = random_stable_plants(rng, batch, n, m, r)
+    for all_elements in (True, False):
+        w3, q = synth.block_weights(m, r, v, 0.3, 0.7, 2.0, all_elements=all_elements)
+        data = dict(A=A, B=B, C=C, W3=w3, Q=q, x0=rng.standard_normal((batch, n)), ref=rng.standard_normal((batch, f * r)),
+                    f=f, v=v)
+        want = oracle_qp(orc, data)
+        for il in (0, 1, 64):
+            got = _run(ctx, data, il)
+            for k in ("Phi", "Gamma", "H", "fvec"):
+                assert_close(got[k], want[k], f"n{n} m{m} r{r} f{f} v{v} W={il} all_elements={all_elements} {k}")
+    # output subsets must equal the full call bit for bit
+    full = _run(ctx, data, 64)
+    for sub in (("Gamma",), ("H", "fvec"), ("Phi", "fvec")):
+        part = _run(ctx, data, 64, want=sub)
+        for k in sub:
+            assert np.array_equal(part[k], full[k]), f"n{n} m{m} r{r}: {k} alone differs from the full call"
+
+
 @pytest.mark.parametrize("n,m,r,f,v", [(12, 4, 12, 10, 10), (12, 4, 12, 9, 4), (8, 2, 2, 40, 40), (8, 2, 2, 30, 7),
                                        (7, 3, 5, 6, 6), (9, 1, 1, 12, 2), (16, 5, 3, 5, 1), (10, 2, 4, 3, 3),
                                        (8, 4, 4, 11, 11), (7, 3, 3, 9, 5), (9, 2, 4, 8, 8), (9, 1, 1, 300, 300),

@@ -69,6 +69,55 @@ def _reserve_then_dev_calls(ctx):
     assert free1 == free0, "a _dev call allocated device memory after mpcx_reserve"
 
 
+def test_reserve_covers_builds_with_fewer_outputs_when_the_relay_cap_binds():
+    """With a small MPCX_OPT_RELAY_CAP_BYTES the instance-major copy holds a whole number of instances under the cap; a
+    build that asks for Gamma alone has a smaller per-instance size, so its chunk holds more instances and chunk x size can
+    exceed what the all-outputs chunk takes.  After mpcx_reserve neither form may allocate."""
+    ctx = ffi.Context(0)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        n, m, r, f, v, il, batch = 8, 2, 2, 40, 40, 64, 256
+        per_full = n * n + n * m + r * n + n + f * r + f * r * n + (f * r) * (v * m) + (v * m) ** 2 + v * m
+        per_gamma = n * n + n * m + r * n + (f * r) * (v * m)
+        cap = 8 * (127 * per_full + per_full // 2)  # all outputs: one group of 64 instances; Gamma alone: four groups
+        assert (cap // (8 * per_gamma)) // 64 * 64 * per_gamma > 64 * per_full
+        ctx.set_option(ffi.OPT_RELAY_CAP_BYTES, cap)
+        rng = np.random.default_rng(12)
+        sp = torch.cuda.current_stream().cuda_stream
+
+        def dv(elems, b):
+            return torch.from_numpy(rng.standard_normal(L.array_elems(b, il, elems)) * 0.1).to(dev)
+        W3 = torch.eye(v * m, dtype=torch.float64, device=dev).contiguous()
+        Q = torch.eye(r, dtype=torch.float64, device=dev).contiguous()
+
+        def run(b, reserve):
+            d = ffi.make_dims(n, m, r, f, v, b, 0, il)
+            A, B, Cm, x0, ref = dv(n * n, b), dv(n * m, b), dv(r * n, b), dv(n, b), dv(f * r, b)
+            Phi, Gam, H, fv = dv(f * r * n, b), dv(f * r * v * m, b), dv((v * m) ** 2, b), dv(v * m, b)
+            Gam2 = torch.zeros_like(Gam)
+            torch.cuda.synchronize()
+            if reserve:
+                ctx.reserve(d)
+                torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info(0)[0]
+            ctx.qp_build_dev(d, A.data_ptr(), B.data_ptr(), Cm.data_ptr(), None, None, None, None, None, Gam2.data_ptr(), None, None, sp)
+            torch.cuda.synchronize()
+            free1 = torch.cuda.mem_get_info(0)[0]
+            ctx.qp_build_dev(d, A.data_ptr(), B.data_ptr(), Cm.data_ptr(), W3.data_ptr(), Q.data_ptr(), x0.data_ptr(), ref.data_ptr(),
+                             Phi.data_ptr(), Gam.data_ptr(), H.data_ptr(), fv.data_ptr(), sp)
+            torch.cuda.synchronize()
+            free2 = torch.cuda.mem_get_info(0)[0]
+            assert torch.equal(Gam, Gam2)  # chunking differs between the two calls, the results must not
+            return free0, free1, free2
+        run(1, reserve=False)  # code objects loaded
+        free0, free1, free2 = run(batch, reserve=True)
+        assert free1 == free0, "the Gamma-only build allocated after mpcx_reserve"
+        assert free2 == free0, "the all-outputs build allocated after mpcx_reserve"
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4])
 def test_small_systems_closed_form_as_try_inverse(ctx, k):
     rng = np.random.default_rng(40 + k)
@@ -124,3 +173,29 @@ def test_c2d_small_plants_flag_what_the_closed_form_flags(ctx, n):
         _, Aw, Bw = orc.c2d_backward_euler(Ac[b], Bc[b], dt)
         tol = 1e-10 * max(np.linalg.cond(np.eye(n) - Ac[b] * dt), 1.0)
         assert np.linalg.norm(A[b] - Aw) <= tol * np.linalg.norm(Aw) and np.linalg.norm(B[b] - Bw) <= tol * max(np.linalg.norm(Bw), 1e-300)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_c2d_with_three_inputs_rounds_the_product_before_the_subtraction(ctx, n):
+    """n <= 4 with m = 3 has no one-lane instantiation and goes through the general path.  `identity - mat_ac.scale(dt)`
+    (model.rs:56) rounds Ac dt first: with Ac[0][0] = 3 and dt = 1/3 the product rounds to exactly 1, the first row and
+    column of I - Ac dt vanish and try_inverse fails on a zero determinant; a fused multiply-subtract would leave 2^-54
+    there and invert.  Flags must be the oracle's, instance by instance."""
+    rng = np.random.default_rng(170 + n)
+    nb, dt = 96, 1.0 / 3.0
+    assert 3.0 * dt == 1.0 and np.float64(3.0) * np.float64(dt) == 1.0
+    Ac = rng.standard_normal((nb, n, n)) - 2.0 * np.eye(n)
+    for b in range(0, nb, 4):
+        Ac[b, 0, :] = 0.0
+        Ac[b, :, 0] = 0.0
+        Ac[b, 0, 0] = 3.0
+    Bc = rng.standard_normal((nb, n, 3))
+    for il in (0, 1):
+        A, B, info = ctx.c2d(Ac, Bc, dt, interleave=il)
+        st = np.array([orc.c2d_backward_euler(Ac[b], Bc[b], dt)[0] for b in range(nb)])
+        assert np.array_equal(info != 0, st != orc.ORC_OK)
+        assert (info != 0).sum() == nb // 4
+        for b in np.nonzero(info == 0)[0]:
+            _, Aw, Bw = orc.c2d_backward_euler(Ac[b], Bc[b], dt)
+            tol = 1e-10 * max(np.linalg.cond(np.eye(n) - Ac[b] * dt), 1.0)
+            assert np.linalg.norm(A[b] - Aw) <= tol * np.linalg.norm(Aw) and np.linalg.norm(B[b] - Bw) <= tol * max(np.linalg.norm(Bw), 1e-300)

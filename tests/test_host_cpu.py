@@ -54,6 +54,25 @@ def test_rust_sys_crate_declares_the_same_abi():
         assert m and int(m.group(1)) == int(value), f"{name} differs between the header and the Rust crate"
 
 
+def test_rust_build_script_compiles_the_sources_the_makefile_compiles():
+    """rust/mpcx-sys/build.rs and the build.rs shown in INTEGRATION.md drive hipcc themselves: their source lists must be
+    the Makefile's SRCS (a list that misses a file yields a libmpcx.so without the symbols lib.rs declares), and both must
+    link libdl, which comm.hip needs for its late binding of RCCL."""
+    mk = open(os.path.join(ROOT, "mpc-rs_amd", "csrc", "Makefile")).read()
+    srcs = re.search(r"^SRCS\s*:=\s*(.*)$", mk, flags=re.M).group(1).split()
+    assert srcs and all(os.path.exists(os.path.join(ROOT, "mpc-rs_amd", "csrc", f)) for f in srcs)
+    assert "-ldl" in mk
+    rs = open(os.path.join(ROOT, "rust", "mpcx-sys", "build.rs")).read()
+    m = re.search(r"const SOURCES: \[&str; (\d+)\] = \[(.*?)\];", rs, flags=re.S)
+    listed = re.findall(r'"([^"]+\.hip)"', m.group(2))
+    assert listed == srcs and int(m.group(1)) == len(srcs)
+    assert '"-ldl"' in rs
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"let src = \[(.*?)\];", doc, flags=re.S)
+    assert re.findall(r'"([^"]+\.hip)"', m.group(1)) == srcs
+    assert '"-ldl"' in doc
+
+
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(ffi.Dims) == 8 * 4 + 3 * 8
     assert ctypes.sizeof(ffi.Stats) == 48
