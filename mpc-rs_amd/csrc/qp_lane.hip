@@ -18,6 +18,11 @@
 //   F = V = 0   horizons are run-time values; the Markov blocks and z live in LDS, one column of slots per lane.
 //   F, V > 0    horizons are compile-time; every loop unrolls, the Markov blocks and z live in registers (no LDS) and the
 //               instruction stream is little more than the FMAs and the stores.
+// A third style, PAD: N, M, R are upper bounds and the plant's own n <= N, m <= M, r <= R are run-time values.  The
+// register arrays and the unrolled loops keep the padded extents (rows and columns beyond the plant's are zero and take
+// part in the arithmetic as zeros); memory and LDS are indexed with n, m, r, and every access beyond them is skipped.
+// It serves the small plants that have no exact instantiation at the price of the padded multiply-adds, which a kernel
+// bound by its stores can afford.
 // Addressing: every output is walked with a running pointer (wave-uniform when UNI) plus a fixed 32-bit lane
 // offset, so a store costs one vector instruction and a scalar pointer bump.
 #include "mpcx_internal.h"
@@ -42,14 +47,14 @@ struct LaneOut {
 // UNI: every lane of a wavefront lies in the same interleave tile (W is a multiple of 64, or W >= batch), so the
 // tile offset is wave-uniform and each access is "scalar base + 32-bit lane offset".
 // OUT: 0 = test the output pointers at run time; 15 = all four outputs are present (no tests in the stream).
-template <int N, int M, int R, bool UNI, int F, int V, int OUT>
+template <int N, int M, int R, bool UNI, int F, int V, int OUT, bool PAD = false>
 __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(const double *__restrict__ gA, const double *__restrict__ gB,
                                                              const double *__restrict__ gC,
                                                              const double *__restrict__ gW3,
                                                              const double *__restrict__ gW4,
                                                              const double *__restrict__ gx0,
                                                              const double *__restrict__ gref, LaneOut p, long long batch,
-                                                             long long W, int rt_f, int rt_v) {
+                                                             long long W, int rt_f, int rt_v, int rt_n, int rt_m, int rt_r) {
     extern __shared__ double lds[];  // [slot][kLaneBlock]; lane t owns lds[slot * kLaneBlock + t]
     constexpr bool STATIC = (F > 0);
     const bool wPhi = OUT ? true : p.Phi != nullptr, wGamma = OUT ? true : p.Gamma != nullptr;
@@ -62,7 +67,13 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
     if (UNI) tile = (long long)__builtin_amdgcn_readfirstlane((int)tile);
     const unsigned lane_byte = UNI ? (unsigned)lane_ll * 8u : 0u;
     const int f = STATIC ? F : rt_f, v = STATIC ? V : rt_v;
-    const int FR = f * R, VM = v * M;
+    static_assert(!(PAD && F > 0), "padded shapes take run-time horizons");
+    // the plant's own extents: compile-time constants unless PAD
+    const int n = PAD ? rt_n : N, m = PAD ? rt_m : M, r = PAD ? rt_r : R;
+#define IN_N(i) (!PAD || (i) < n)
+#define IN_M(c) (!PAD || (c) < m)
+#define IN_R(a) (!PAD || (a) < r)
+    const int FR = f * r, VM = v * m;
     const long long stride = W * 8;  // bytes between consecutive elements of one instance
 
     // base pointer of this lane's instance in an array of E elements per instance (wave-uniform when UNI)
@@ -74,27 +85,28 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
     // SIMD).  Measured against z in LDS at four waves per SIMD: 1.433 vs 1.454 ms for 2^20 two-mass instances.
     double greg[STATIC ? F * R * M : 1];
     double zreg[STATIC ? F * R : 1];
-    const int zbase = STATIC ? 0 : f * R * M;
+    const int zbase = STATIC ? 0 : f * r * m;
+    // (PAD: only entries with a < r, c < m exist)
 #define LG(k, a, c) \
-    (*(STATIC ? &greg[STATIC ? (((k) * R + (a)) * M + (c)) : 0] : &lds[(((k) * R + (a)) * M + (c)) * kLaneBlock + tid]))
-#define LZ(i, a) (*(STATIC ? &zreg[STATIC ? ((i) * R + (a)) : 0] : &lds[(zbase + (i) * R + (a)) * kLaneBlock + tid]))
+    (*(STATIC ? &greg[STATIC ? (((k) * R + (a)) * M + (c)) : 0] : &lds[(((k) * r + (a)) * m + (c)) * kLaneBlock + tid]))
+#define LZ(i, a) (*(STATIC ? &zreg[STATIC ? ((i) * R + (a)) : 0] : &lds[(zbase + (i) * r + (a)) * kLaneBlock + tid]))
 
     double A[N][N], Bm[N][M], Cm[R][N];
     {
         const unsigned lb = keep_local(lane_byte);
-        const char *bA = BASE(gA, N * N), *bB = BASE(gB, N * M), *bC = BASE(gC, R * N);
+        const char *bA = BASE(gA, n * n), *bB = BASE(gB, n * m), *bC = BASE(gC, r * n);
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int i = 0; i < N; ++i) A[i][j] = AT(bA, j * N + i);
+            for (int i = 0; i < N; ++i) A[i][j] = (IN_N(i) && IN_N(j)) ? AT(bA, j * n + i) : 0.0;
 #pragma unroll
         for (int j = 0; j < M; ++j)
 #pragma unroll
-            for (int i = 0; i < N; ++i) Bm[i][j] = AT(bB, j * N + i);
+            for (int i = 0; i < N; ++i) Bm[i][j] = (IN_N(i) && IN_M(j)) ? AT(bB, j * n + i) : 0.0;
 #pragma unroll
         for (int j = 0; j < N; ++j)
 #pragma unroll
-            for (int i = 0; i < R; ++i) Cm[i][j] = AT(bC, j * R + i);
+            for (int i = 0; i < R; ++i) Cm[i][j] = (IN_R(i) && IN_N(j)) ? AT(bC, j * r + i) : 0.0;
     }
 
     const bool need_g = wGamma || wH || wf;
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
 #pragma unroll
     for (int j = 0; j < R; ++j)
 #pragma unroll
-        for (int i = 0; i < R; ++i) Q[i][j] = need_q ? gW4[j * R + i] : 0.0;
+        for (int i = 0; i < R; ++i) Q[i][j] = (need_q && IN_R(i) && IN_R(j)) ? gW4[j * r + i] : 0.0;
 
     // Every global load is issued before the first global store: loads and stores retire through one in-order
     // counter, so a load placed after stores would wait for all of them.
@@ -112,13 +124,15 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
     for (int i = 0; i < N; ++i) x0[i] = 0.0;
     if (wf) {
         const unsigned lb = keep_local(lane_byte);
-        const char *bx = BASE(gx0, N), *br = BASE(gref, FR);
+        const char *bx = BASE(gx0, n), *br = BASE(gref, FR);
 #pragma unroll
-        for (int i = 0; i < N; ++i) x0[i] = AT(bx, i);
+        for (int i = 0; i < N; ++i)
+            if (IN_N(i)) x0[i] = AT(bx, i);
 #pragma unroll
         for (int i = 0; i < (STATIC ? F : f); ++i)
 #pragma unroll
             for (int a = 0; a < R; ++a) {
+                if (!IN_R(a)) continue;
                 LZ(i, a) = HERE(br);
                 br += stride;
             }
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                     double g = 0.0;
 #pragma unroll
                     for (int j = 0; j < N; ++j) g += Cm[a][j] * w[j][c];
-                    LG(k, a, c) = g;
+                    if (IN_R(a) && IN_M(c)) LG(k, a, c) = g;
                 }
             double wn[N][M];
 #pragma unroll
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
             for (int j = 0; j < N; ++j) P[a][j] = Cm[a][j];
         char *pphi[N];  // one running pointer per column of Phi
         {
-            char *bPhi = wPhi ? BASE(p.Phi, (long long)FR * N) : nullptr;
+            char *bPhi = wPhi ? BASE(p.Phi, (long long)FR * n) : nullptr;
 #pragma unroll
             for (int j = 0; j < N; ++j) pphi[j] = bPhi + (long long)j * FR * stride;
         }
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                 for (int j = 0; j < N; ++j)
 #pragma unroll
                     for (int a = 0; a < R; ++a) {
+                        if (!(IN_N(j) && IN_R(a))) continue;
                         HERE(pphi[j]) = P[a][j];
                         pphi[j] += stride;
                     }
@@ -206,14 +221,14 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                     double acc = 0.0;
 #pragma unroll
                     for (int j = 0; j < N; ++j) acc += P[a][j] * x0[j];
-                    s[a] = acc - LZ(i, a);  // the slot holds ref_i until z_i replaces it
+                    s[a] = IN_R(a) ? acc - LZ(i, a) : 0.0;  // the slot holds ref_i until z_i replaces it
                 }
 #pragma unroll
                 for (int a = 0; a < R; ++a) {
                     double z = 0.0;
 #pragma unroll
                     for (int q = 0; q < R; ++q) z += Q[a][q] * s[q];
-                    LZ(i, a) = z;
+                    if (IN_R(a)) LZ(i, a) = z;
                 }
             }
         }
@@ -238,9 +253,11 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                 if (STATIC && i < k) continue;  // constant trip count, so that the nest unrolls fully
 #pragma unroll
                 for (int a = 0; a < R; ++a) {
+                    if (!IN_R(a)) continue;
                     const double z = LZ(i, a);
 #pragma unroll
                     for (int c = 0; c < M; ++c) {
+                        if (!IN_M(c)) continue;
                         const double g = LG(i - k, a, c);
                         run[a][c] += g;
                         acc[c] += (last ? run[a][c] : g) * z;
@@ -249,6 +266,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
             }
 #pragma unroll
             for (int c = 0; c < M; ++c) {
+                if (!IN_M(c)) continue;
                 HERE(pf) = acc[c];
                 pf += stride;
             }
@@ -263,6 +281,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
             const bool last = (k == v - 1);
 #pragma unroll
             for (int c = 0; c < M; ++c) {
+                if (!IN_M(c)) continue;
                 double run[R];  // running sum S for the held-input column
 #pragma unroll
                 for (int a = 0; a < R; ++a) run[a] = 0.0;
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                 for (int i = 0; i < (STATIC ? F : f); ++i) {
 #pragma unroll
                     for (int a = 0; a < R; ++a) {
+                        if (!IN_R(a)) continue;
                         double val = 0.0;
                         if (i >= k) {
                             const double g = LG(i - k, a, c);
@@ -293,7 +313,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
         const unsigned lb = keep_local(lane_byte);
         double hreg[STATIC ? V * M * M : 1];
 #define HP(a, i, j) \
-    (*(STATIC ? &hreg[STATIC ? (((a) * M + (i)) * M + (j)) : 0] : &lds[(zbase + ((a) * M + (i)) * M + (j)) * kLaneBlock + tid]))
+    (*(STATIC ? &hreg[STATIC ? (((a) * M + (i)) * M + (j)) : 0] : &lds[(zbase + ((a) * m + (i)) * m + (j)) * kLaneBlock + tid]))
         char *bH = BASE(p.H, (long long)VM * VM);
 #pragma unroll
         for (int bb = (STATIC ? V : v) - 1; bb >= 0; --bb) {
@@ -308,16 +328,19 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                         for (int c = 0; c < M; ++c) {
                             double sq = 0.0;
 #pragma unroll
-                            for (int q = 0; q < R; ++q) sq += Q[a][q] * LG(f - 1 - bb, q, c);
+                            for (int q = 0; q < R; ++q)
+                                if (IN_R(q) && IN_M(c)) sq += Q[a][q] * LG(f - 1 - bb, q, c);
                             qg[a][c] = sq;
                         }
 #pragma unroll
                     for (int i = 0; i < M; ++i)
 #pragma unroll
                         for (int j = 0; j < M; ++j) {
+                            if (!(IN_M(i) && IN_M(j))) continue;
                             double t = HP(aa + 1, i, j);
 #pragma unroll
-                            for (int a = 0; a < R; ++a) t += LG(f - 1 - aa, a, i) * qg[a][j];
+                            for (int a = 0; a < R; ++a)
+                                if (IN_R(a)) t += LG(f - 1 - aa, a, i) * qg[a][j];
                             acc[i][j] = t;
                         }
                 } else {
@@ -340,6 +363,11 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                         for (int a = 0; a < R; ++a)
 #pragma unroll
                             for (int c = 0; c < M; ++c) {
+                                if (!(IN_R(a) && IN_M(c))) {
+                                    xa[a][c] = 0.0;
+                                    xb[a][c] = 0.0;
+                                    continue;
+                                }
                                 if (la || lbk) S[a][c] += LG(i2 - (v - 1), a, c);
                                 xa[a][c] = la ? S[a][c] : LG(i2 - aa, a, c);
                                 xb[a][c] = lbk ? S[a][c] : LG(i2 - bb, a, c);
@@ -364,17 +392,20 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
 #pragma unroll
                 for (int i = 0; i < M; ++i)
 #pragma unroll
-                    for (int j = 0; j < M; ++j) HP(aa, i, j) = acc[i][j];
+                    for (int j = 0; j < M; ++j)
+                        if (IN_M(i) && IN_M(j)) HP(aa, i, j) = acc[i][j];
             }
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                char *ph = bH + (long long)(bb * M + j) * VM * stride;
-                const double *w3 = gW3 + (long long)(bb * M + j) * VM;
+                if (!IN_M(j)) continue;
+                char *ph = bH + (long long)(bb * m + j) * VM * stride;
+                const double *w3 = gW3 + (long long)(bb * m + j) * VM;
 #pragma unroll
                 for (int aa = 0; aa < (STATIC ? V : v); ++aa)
 #pragma unroll
                     for (int i = 0; i < M; ++i) {
-                        HERE(ph) = HP(aa, i, j) + w3[aa * M + i];
+                        if (!IN_M(i)) continue;
+                        HERE(ph) = HP(aa, i, j) + w3[aa * m + i];
                         ph += stride;
                     }
             }
@@ -387,22 +418,31 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
 #undef HERE
 #undef LG
 #undef LZ
+#undef IN_N
+#undef IN_M
+#undef IN_R
 }
 
-template <int N, int M, int R, bool UNI, int F, int V, int OUT>
+template <int N, int M, int R, bool UNI, int F, int V, int OUT, bool PAD = false>
 int launch_k(const QpArgs &a, size_t lds_bytes, unsigned blocks, hipStream_t s) {
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)qp_lane_kernel<N, M, R, UNI, F, V, OUT>,
+        hipError_t e = hipFuncSetAttribute((const void *)qp_lane_kernel<N, M, R, UNI, F, V, OUT, PAD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
     LaneOut o{a.Phi, a.Gamma, a.H, a.fvec};
-    hipLaunchKernelGGL((qp_lane_kernel<N, M, R, UNI, F, V, OUT>), dim3(blocks), dim3(kLaneBlock), lds_bytes, s, a.A, a.B, a.C,
-                       a.W3, a.W4, a.x0, a.ref, o, a.batch, a.W, a.f, a.v);
+    hipLaunchKernelGGL((qp_lane_kernel<N, M, R, UNI, F, V, OUT, PAD>), dim3(blocks), dim3(kLaneBlock), lds_bytes, s, a.A, a.B, a.C,
+                       a.W3, a.W4, a.x0, a.ref, o, a.batch, a.W, a.f, a.v, a.n, a.m, a.r);
     return (int)hipGetLastError();
 }
 
-template <int N, int M, int R>
+// LDS bytes of the run-time-horizon form: Markov blocks + max(z, one column block of H), one slot column per lane
+size_t lane_lds_bytes(const QpArgs &a) {
+    const size_t zh = (size_t)a.f * a.r > (size_t)a.v * a.m * a.m ? (size_t)a.f * a.r : (size_t)a.v * a.m * a.m;
+    return ((size_t)a.f * a.r * a.m + zh) * kLaneBlock * sizeof(double);
+}
+
+template <int N, int M, int R, bool PAD = false>
 int launch_one(const QpArgs &a, hipStream_t s) {
     const long long blocks = (a.batch + kLaneBlock - 1) / kLaneBlock;
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
@@ -410,17 +450,15 @@ int launch_one(const QpArgs &a, hipStream_t s) {
     const bool uni = ((a.W % kLaneBlock) == 0 || a.W >= a.batch) && a.W <= (1LL << 28);
     // register-resident specialisation for the horizon the reference's own scenario uses (main.rs:22-23)
     const bool all = a.Phi && a.Gamma && a.H && a.fvec;
-    if constexpr (M == 1 && R == 1 && (N == 2 || N == 4)) {
+    if constexpr (!PAD && M == 1 && R == 1 && (N == 2 || N == 4)) {
         if (uni && all && a.f == 20 && a.v == 20)
             return launch_k<N, M, R, true, 20, 20, 15>(a, 0, (unsigned)blocks, s);
     }
-    const size_t zh = (size_t)a.f * R > (size_t)a.v * M * M ? (size_t)a.f * R : (size_t)a.v * M * M;
-    const size_t slots = (size_t)a.f * R * M + zh;  // Markov blocks + max(z, one column block of H)
-    const size_t lds_bytes = slots * kLaneBlock * sizeof(double);
+    const size_t lds_bytes = lane_lds_bytes(a);
     if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
-    if (uni && all) return launch_k<N, M, R, true, 0, 0, 15>(a, lds_bytes, (unsigned)blocks, s);
-    return uni ? launch_k<N, M, R, true, 0, 0, 0>(a, lds_bytes, (unsigned)blocks, s)
-               : launch_k<N, M, R, false, 0, 0, 0>(a, lds_bytes, (unsigned)blocks, s);
+    if (uni && all) return launch_k<N, M, R, true, 0, 0, 15, PAD>(a, lds_bytes, (unsigned)blocks, s);
+    return uni ? launch_k<N, M, R, true, 0, 0, 0, PAD>(a, lds_bytes, (unsigned)blocks, s)
+               : launch_k<N, M, R, false, 0, 0, 0, PAD>(a, lds_bytes, (unsigned)blocks, s);
 }
 
 }  // namespace
@@ -433,12 +471,15 @@ bool qp_lane_supports(int n, int m, int r) {
     return false;
 }
 
+// Small plants without an exact instantiation ride a padded one: <6,2,2> or <6,3,3> with the plant's own extents at
+// run time.
+bool qp_lane_padded(int n, int m, int r) { return n >= 1 && n <= 6 && m >= 1 && m <= 3 && r >= 1 && r <= 3; }
+
 bool qp_lane_takes(const QpArgs &a) {
     if (a.weights_mode != MPCX_WEIGHTS_BLOCK && (a.H || a.fvec)) return false;
-    if (!qp_lane_supports(a.n, a.m, a.r)) return false;
+    if (!qp_lane_supports(a.n, a.m, a.r) && !qp_lane_padded(a.n, a.m, a.r)) return false;
     if ((a.batch + kLaneBlock - 1) / kLaneBlock > 0x7fffffffLL) return false;
-    const size_t zh = (size_t)a.f * a.r > (size_t)a.v * a.m * a.m ? (size_t)a.f * a.r : (size_t)a.v * a.m * a.m;
-    return ((size_t)a.f * a.r * a.m + zh) * kLaneBlock * sizeof(double) <= 160 * 1024;  // as launch_one sizes its LDS
+    return lane_lds_bytes(a) <= 160 * 1024;  // as launch_one sizes its LDS
 }
 
 int launch_qp_lane(const QpArgs &a, hipStream_t s) {
@@ -449,7 +490,8 @@ int launch_qp_lane(const QpArgs &a, hipStream_t s) {
     CASE(2, 2, 2) CASE(4, 2, 2) CASE(6, 2, 2)
     CASE(3, 2, 1) CASE(4, 2, 1) CASE(3, 1, 2) CASE(4, 1, 2)
 #undef CASE
-    return MPCX_ERR_UNSUPPORTED;
+    if (a.m <= 2 && a.r <= 2) return launch_one<6, 2, 2, true>(a, s);
+    return launch_one<6, 3, 3, true>(a, s);
 }
 
 }  // namespace mpcx

@@ -94,7 +94,8 @@ def test_reserve_covers_builds_with_fewer_outputs_when_the_relay_cap_binds():
         def run(b, reserve):
             d = ffi.make_dims(n, m, r, f, v, b, 0, il)
             A, B, Cm, x0, ref = dv(n * n, b), dv(n * m, b), dv(r * n, b), dv(n, b), dv(f * r, b)
-            Phi, Gam, H, fv = dv(f * r * n, b), dv(f * r * v * m, b), dv((v * m) ** 2, b), dv(v * m, b)
+            Phi, H, fv = dv(f * r * n, b), dv((v * m) ** 2, b), dv(v * m, b)
+            Gam = torch.zeros(L.array_elems(b, il, f * r * v * m), dtype=torch.float64, device=dev)  # (padding lanes stay zero)
             Gam2 = torch.zeros_like(Gam)
             torch.cuda.synchronize()
             if reserve:
