@@ -56,6 +56,11 @@ def bytes_gain(m, r, f, v):
     return 8 * ((v * m) ** 2 + 2 * f * r * v * m) + 4
 
 
+def bytes_gain_rows(m, r, f, v):
+    # H and Gamma read, the first m rows of the gain stored
+    return 8 * ((v * m) ** 2 + f * r * v * m + m * f * r) + 4
+
+
 def bytes_loop(n, m, r, f, T):
     # A, B, C, x0, Phi, the first m rows of the gain; X, U, Y stored; the reference trajectory is shared
     return 8 * (n * n + n * m + r * n + n + f * r * n + m * f * r + n * (T + 1) + m * T + r * T)
@@ -71,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="two_mass", choices=sorted(DEFAULT_BATCH))
-    ap.add_argument("--op", default="qp", choices=["qp", "rollout", "solve", "gain", "loop", "plants"])
+    ap.add_argument("--op", default="qp", choices=["qp", "rollout", "solve", "gain", "gain_rows", "loop", "plants"])
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the workload's own)")
     ap.add_argument("--interleave", type=int, default=-1, help="-1: layout the kernels are native in")
     ap.add_argument("--f", type=int, default=0, help="prediction horizon override (default: the workload's)")
@@ -190,7 +195,7 @@ def main():
             unit_bytes = 8 * (6 + 16 + 4 + 4) + 4
             metric, unit = "batched plant constructions/sec (parameters -> A,B,C)", "plants/s"
             check_buf = outs["A"]
-        elif op in ("solve", "gain", "loop"):
+        elif op in ("solve", "gain", "gain_rows", "loop"):
             # operands come from a device-side build (and gain solve) outside the timed region
             qp = {"Phi": out(f * r * n), "Gamma": out(f * r * v * m), "H": out(v * m * v * m), "fvec": out(v * m)}
             dims = ffi.make_dims(n, m, r, f, v, count, T, il, u_shared=1)
@@ -198,7 +203,16 @@ def main():
                              bufs["Q"].data_ptr(), bufs["x0"].data_ptr(), bufs["ref"].data_ptr(), qp["Phi"].data_ptr(),
                              qp["Gamma"].data_ptr(), qp["H"].data_ptr(), qp["fvec"].data_ptr(), sp)
             info = torch.zeros(count, dtype=torch.int32, device=dev)
-            if op == "solve":
+            if op == "gain_rows":
+                outs = {"rows": out(m * f * r)}
+
+                def step():
+                    ctx.qp_gain_rows_dev(dims, qp["H"].data_ptr(), qp["Gamma"].data_ptr(), bufs["Q"].data_ptr(),
+                                         outs["rows"].data_ptr(), info.data_ptr(), sp)
+                unit_bytes = bytes_gain_rows(m, r, f, v)
+                metric, unit = "batched MPC first-move gain rows/sec (rows 0..m-1 of H^-1 Gamma^T W4)", "gains/s"
+                check_buf = outs["rows"]
+            elif op == "solve":
                 outs = {"u_seq": out(v * m)}
 
                 def step():
@@ -383,7 +397,7 @@ def main():
             res["lib_gather"] = lib_gather
         if mfma_ms is not None:
             res["roofline"] = _mfma_roofline(case, mfma_ms, kernel_ms, achieved)
-        if args.op in ("solve", "gain", "loop", "plants"):
+        if args.op in ("solve", "gain", "gain_rows", "loop", "plants"):
             res["check"]["singular_instances"] = int((case.info != 0).sum().item())
         if world == 1 and not args.no_cpu_baseline and args.op in ("qp", "rollout"):
             res["cpu_baseline"] = _cpu_baseline(args, case.d, n, m, r, f, v, T, case.unit, outs, il, count)
@@ -452,7 +466,8 @@ ALSO = (("msd", "qp", 0, 0, 0), ("quadrotor", "qp", 0, 0, 0), ("long", "qp", 0, 
         ("long", "qp", 0, 0, 1),                                        # H as the FP64 matrix-core contraction
         ("msd", "rollout", 0, 0, 0), ("two_mass", "rollout", 0, 0, 0), ("quadrotor", "rollout", 0, 0, 0),
         ("two_mass", "solve", 0, 0, 0), ("two_mass", "gain", 0, 0, 0), ("two_mass", "loop", 0, 0, 0),
-        ("quadrotor", "loop", 0, 0, 0), ("quadrotor", "gain", 0, 0, 0), ("long", "gain", 0, 0, 0))
+        ("quadrotor", "loop", 0, 0, 0), ("quadrotor", "gain", 0, 0, 0), ("long", "gain", 0, 0, 0),
+        ("two_mass", "gain_rows", 0, 0, 0), ("quadrotor", "gain_rows", 0, 0, 0), ("long", "gain_rows", 0, 0, 0))
 ALSO_BUDGET_S = 120.0  # the extras take about 25 s; beyond this something has regressed and the run fails
 
 def _mfma_roofline(case, mfma_ms, step_ms, achieved_bytes_per_s):

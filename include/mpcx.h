@@ -181,6 +181,20 @@ int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, 
                          double *gain, int32_t *info, void *stream);
 
 /*
+ * First-move rows of the gain, batched: the first m rows of gain_matrix = H^-1 Gamma^T W4 (controller.rs:93-96), which is
+ * all that compute_control_input applies (controller.rs:130-132 takes u_seq[0] of gain s; for m inputs its first m
+ * entries).  Computed as m solves with H^T (right-hand sides e_0 .. e_(m-1)) and one product with Gamma^T W4 instead of
+ * f r solves, so the cost is that of the factorisation.  gain_rows is m x (f r) per instance, column-major, in
+ * dims->interleave: exactly what mpcx_closed_loop_* takes as `gain` when its dims->v is set to 1 (a (1 m) x (f r) gain).
+ * Same weights_mode, pivoting, `info` semantics and limits as mpcx_qp_gain; failed instances hold NaN.  Additive: the
+ * reference always forms the whole gain.
+ */
+int mpcx_qp_gain_rows_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *Gamma, const double *W4,
+                          double *gain_rows, int32_t *info);
+int mpcx_qp_gain_rows_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *Gamma, const double *W4,
+                              double *gain_rows, int32_t *info, void *stream);
+
+/*
  * Backward-Euler discretisation, batched: A = (I - Ac dt)^-1, B = A (Bc dt), the last three lines of both
  * Model::new (model.rs:55-57, :138-140).  Ac is n x n, Bc n x m per instance (dims->n, m, batch, interleave).
  * `info` as for mpcx_qp_solve: 1 marks an instance whose matrix could not be inverted (the reference unwraps the

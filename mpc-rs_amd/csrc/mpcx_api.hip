@@ -16,7 +16,7 @@ struct mpcx_ctx {
     size_t work_bytes;
     void *lu_work;       // augmented matrices of the blocked solver (systems beyond 64 unknowns)
     size_t lu_bytes;
-    void *aux;           // I - Ac dt of the general discretisation
+    void *aux;           // I - Ac dt of the general discretisation; the solutions H^-T e_i of the first-move gain rows
     size_t aux_bytes;
     void *stat_scratch;  // partial records of the stats reduction + one result record
     void *relay;         // instance-major copy of a chunk of the batch (interleaved data on the workgroup kernels)
@@ -96,6 +96,18 @@ int ensure_work(mpcx_ctx *ctx, size_t bytes) {
     }
     HIP_TRY(ctx, hipMalloc(&ctx->work, bytes));
     ctx->work_bytes = bytes;
+    return MPCX_OK;
+}
+
+int ensure_aux(mpcx_ctx *ctx, size_t need) {
+    if (need <= ctx->aux_bytes) return MPCX_OK;
+    if (ctx->aux) {
+        HIP_TRY(ctx, hipFree(ctx->aux));
+        ctx->aux = nullptr;
+        ctx->aux_bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->aux, need));
+    ctx->aux_bytes = need;
     return MPCX_OK;
 }
 
@@ -339,15 +351,14 @@ int mpcx_reserve(mpcx_ctx *ctx, const mpcx_dims *d) {
     if ((rc = ensure_lu_work(ctx, d->v * d->m, 1, d->batch, &wsd)) != MPCX_OK) return rc;
     if ((rc = ensure_lu_work(ctx, d->v * d->m, d->f * d->r, d->batch, &wsd)) != MPCX_OK) return rc;
     if ((rc = ensure_lu_work(ctx, d->n, d->n, d->batch, &wsd)) != MPCX_OK) return rc;
+    if ((rc = ensure_lu_work(ctx, d->v * d->m, d->m, d->batch, &wsd)) != MPCX_OK) return rc;  // first-move gain rows
+    if ((rc = ensure_aux(ctx, (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->v * d->m * d->m) * sizeof(double))) != MPCX_OK)
+        return rc;
     QpArgs a{};
     a.n = d->n; a.m = d->m; a.r = d->r; a.f = d->f; a.v = d->v; a.batch = d->batch; a.W = W; a.weights_mode = d->weights_mode;
     if (!c2d_lane_supports(d->n, d->m)) {  // I - Ac dt of the general discretisation
         const size_t need = (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n) * sizeof(double);
-        if (need > ctx->aux_bytes) {
-            if (ctx->aux) { HIP_TRY(ctx, hipFree(ctx->aux)); ctx->aux = nullptr; ctx->aux_bytes = 0; }
-            HIP_TRY(ctx, hipMalloc(&ctx->aux, need));
-            ctx->aux_bytes = need;
-        }
+        if ((rc = ensure_aux(ctx, need)) != MPCX_OK) return rc;
     }
     if (W != 1 && (!qp_lane_takes(a) || d->hessian_algo == MPCX_HESSIAN_CONTRACT)) {  // instance-major copy of a build
         const long long n = d->n, m = d->m, r = d->r, FR = (long long)d->f * r, VM = (long long)d->v * m;
@@ -610,6 +621,31 @@ int mpcx_qp_gain_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, con
     return MPCX_OK;
 }
 
+int mpcx_qp_gain_rows_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *Gamma, const double *W4,
+                              double *gain_rows, int32_t *info, void *stream) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->f < 1 || d->v < 1 || d->v > d->f) return fail(ctx, MPCX_ERR_DIMS, "need f >= 1 and 1 <= v <= f");
+    if (d->weights_mode != MPCX_WEIGHTS_BLOCK && d->weights_mode != MPCX_WEIGHTS_DENSE)
+        return fail(ctx, MPCX_ERR_DIMS, "unknown weights_mode %d", d->weights_mode);
+    if (d->batch == 0) return MPCX_OK;
+    if (!H || !Gamma || !W4 || !gain_rows) return fail(ctx, MPCX_ERR_NULL, "H, Gamma, W4 and gain_rows are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t wsd = 0;
+    rc = ensure_lu_work(ctx, d->v * d->m, d->m, d->batch, &wsd);
+    if (rc != MPCX_OK) return rc;
+    rc = ensure_aux(ctx, (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->v * d->m * d->m) * sizeof(double));
+    if (rc != MPCX_OK) return rc;
+    rc = launch_qp_gain_rows(H, Gamma, W4, d->weights_mode == MPCX_WEIGHTS_DENSE, gain_rows, info, d->batch, W, d->m, d->r, d->f,
+                             d->v, (double *)ctx->aux, (double *)ctx->lu_work, wsd, (hipStream_t)stream);
+    if (rc == MPCX_ERR_UNSUPPORTED)
+        return fail(ctx, rc, "gain rows: v m = %d, m = %d, f r = %d is beyond what the solver or the product kernel holds on chip",
+                    d->v * d->m, d->m, d->f * d->r);
+    if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "gain rows launch");
+    return MPCX_OK;
+}
+
 
 int mpcx_qp_solve_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *fvec, double *u_seq, int32_t *info) {
     long long W = 1;
@@ -652,6 +688,29 @@ int mpcx_qp_gain_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const d
     rc = host_stage(ctx, io);
     if (rc != MPCX_OK) return rc;
     rc = mpcx_qp_gain_f64_dev(ctx, d, io.din[0], io.din[1], io.din[2], io.dout[0], io.dinfo, (void *)ctx->stream);
+    return host_collect(ctx, io, rc);
+}
+
+int mpcx_qp_gain_rows_f64(mpcx_ctx *ctx, const mpcx_dims *d, const double *H, const double *Gamma, const double *W4, double *gain_rows,
+                     int32_t *info) {
+    long long W = 1;
+    int rc = check_common(ctx, d, &W);
+    if (rc != MPCX_OK) return rc;
+    if (d->batch == 0) return MPCX_OK;
+    if (!H || !Gamma || !W4 || !gain_rows) return fail(ctx, MPCX_ERR_NULL, "H, Gamma, W4 and gain_rows are required");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long vm = (long long)d->v * d->m, fr = (long long)d->f * d->r;
+    HostIo io{};
+    io.ni = 3;
+    io.hin[0] = H; io.nin[0] = mpcx_array_elems(d->batch, d->interleave, vm * vm);
+    io.hin[1] = Gamma; io.nin[1] = mpcx_array_elems(d->batch, d->interleave, fr * vm);
+    io.hin[2] = W4; io.nin[2] = (d->weights_mode == MPCX_WEIGHTS_DENSE) ? fr * fr : (long long)d->r * d->r;
+    io.no = 1;
+    io.hout[0] = gain_rows; io.nout[0] = mpcx_array_elems(d->batch, d->interleave, (long long)d->m * fr);
+    io.hinfo = info; io.ninfo = d->batch;
+    rc = host_stage(ctx, io);
+    if (rc != MPCX_OK) return rc;
+    rc = mpcx_qp_gain_rows_f64_dev(ctx, d, io.din[0], io.din[1], io.din[2], io.dout[0], io.dinfo, (void *)ctx->stream);
     return host_collect(ctx, io, rc);
 }
 

@@ -54,8 +54,15 @@ int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *inf
                     double *ws, size_t ws_doubles, hipStream_t s);
 int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double *gain, int *info, long long batch,
                    long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s);
+// transposed = 1 solves with H^T instead (H is read transposed)
 int launch_solve_inplace(const double *H, double *X, int *info, long long batch, long long W, int nr, int nrhs, double *ws,
-                         size_t ws_doubles, hipStream_t s);
+                         size_t ws_doubles, hipStream_t s, int transposed = 0);
+// First m rows of the gain H^-1 Gamma^T W4 (m x f r per instance, column-major): m solves with H^T in `y` (v m x m per
+// instance in the batch layout, scratch), then rows = (Gamma y)^T W4.  W4 is the r x r block or, dense != 0, the
+// (f r) x (f r) matrix.
+int launch_qp_gain_rows(const double *H, const double *Gamma, const double *W4, int dense, double *rows, int *info,
+                        long long batch, long long W, int m, int r, int f, int v, double *y, double *ws, size_t ws_doubles,
+                        hipStream_t s);
 int launch_c2d_lane(const double *Ac, const double *Bc, double dt, double *A, double *B, int *info, long long batch, long long W,
                     int n, int m, hipStream_t s);
 bool c2d_lane_supports(int n, int m);  // launch_c2d_lane takes the shape (no scratch needed)
@@ -73,7 +80,7 @@ int launch_qp_gain_dense(const double *H, const double *Gamma, const double *W4,
 size_t solve_large_ws_doubles(int nr, int nrhs);
 bool solve_large_supports(int nr);
 int launch_solve_large(const double *H, const double *R, const double *Q, int r, double *X, int *info, long long batch,
-                       long long W, int nr, int nrhs, int negate, double *ws, size_t ws_doubles, hipStream_t s);
+                       long long W, int nr, int nrhs, int negate, double *ws, size_t ws_doubles, hipStream_t s, int transposed = 0);
 int launch_closed_loop_lane(const LoopArgs &a, hipStream_t s);
 int launch_closed_loop_group(const LoopArgs &a, hipStream_t s);
 int launch_rollout_lane(const RolloutArgs &a, hipStream_t s);

@@ -30,6 +30,8 @@ struct SolveArgs {
     // formed while loading; Q is r x r.  Otherwise Q = nullptr and R is the (nrow x nrhs) right-hand side itself.
     const double *Q;
     int r;
+    // 1: the system matrix is H^T (H is read transposed): X = +-H^-T R.  What the first-move rows of the gain need.
+    int transposed;
 };
 
 // Systems of 1..4 unknowns: one lane per instance, the inverse in closed form (what nalgebra's try_inverse does for
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(kWave) void solve_tiny_kernel(SolveArgs p) {
         for (int k = 0; k < K; ++k) {
             double x = 0.0;
 #pragma unroll
-            for (int j = 0; j < K; ++j) x += inv[k][j] * rr[j];
+            for (int j = 0; j < K; ++j) x += (p.transposed ? inv[j][k] : inv[k][j]) * rr[j];  // (H^T)^-1 = (H^-1)^T
             p.X[elem_index(b, (long long)c * K + k, ER, p.W)] = ok ? sign * x : nan;
         }
     }
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(kWave) void solve_kernel(SolveArgs p) {
     const long long b = blockIdx.x;
     const int nr = p.nrow, nc = p.nrow + p.nrhs, ld = nr | 1;
     const long long EH = (long long)nr * nr, ER = (long long)nr * p.nrhs;
-    for (int e = lane; e < nr * nr; e += kWave) aug[(e / nr) * ld + (e % nr)] = p.H[elem_index(b, e, EH, p.W)];
+    for (int e = lane; e < nr * nr; e += kWave)
+        aug[p.transposed ? (e % nr) * ld + (e / nr) : (e / nr) * ld + (e % nr)] = p.H[elem_index(b, e, EH, p.W)];
     for (int e = lane; e < nr * p.nrhs; e += kWave) aug[(nr + e / nr) * ld + (e % nr)] = p.R[elem_index(b, e, ER, p.W)];
     lds_barrier();
 
@@ -170,14 +173,15 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs p, int ipb,
     const size_t per_inst = (size_t)nr * ldr;
     const int EH = nr * nr, ER = nr * nrhs;
     // ---- HBM -> LDS (transposing: element e = col * nr + row of a column-major matrix goes to row * ldr + col)
-    auto load = [&](const double *src, int E, int col0) {
+    auto load = [&](const double *src, int E, int col0, bool tr) {  // tr: the square matrix goes in transposed
         if (p.W > 1) {  // instance fastest: one access = the same element of all instances of the block
             const int step = nthreads / ipb, inst = tid % ipb;
             int e = tid / ipb, col = e / nr, row = e - col * nr;
             const int dcol = step / nr, drow = step - dcol * nr;
             const double *sp = src + elem_index(b0 + (inst < live ? inst : 0), 0, E, p.W);  // element e is e * W further
             for (; e < E; e += step) {
-                if (inst < live) rows[inst * per_inst + (size_t)row * ldr + col0 + col] = sp[(long long)e * p.W];
+                if (inst < live)
+                    rows[inst * per_inst + (tr ? (size_t)col * ldr + row : (size_t)row * ldr + col0 + col)] = sp[(long long)e * p.W];
                 col += dcol;
                 row += drow;
                 if (row >= nr) { row -= nr; ++col; }
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs p, int ipb,
                 int e = tid, col = e / nr, row = e - col * nr;
                 const double *sp = src + (b0 + inst) * (long long)E;
                 for (; e < E; e += nthreads) {
-                    rows[inst * per_inst + (size_t)row * ldr + col0 + col] = sp[e];
+                    rows[inst * per_inst + (tr ? (size_t)col * ldr + row : (size_t)row * ldr + col0 + col)] = sp[e];
                     col += dcol;
                     row += drow;
                     if (row >= nr) { row -= nr; ++col; }
@@ -196,9 +200,9 @@ __global__ __launch_bounds__(1024) void solve_small_kernel(SolveArgs p, int ipb,
             }
         }
     };
-    load(p.H, EH, 0);
+    load(p.H, EH, 0, p.transposed != 0);
     if (p.Q == nullptr) {
-        load(p.R, ER, nr);
+        load(p.R, ER, nr, false);
     } else {
         // right-hand side column c = (blk, a2), row k:  sum_a Gamma[blk r + a][k] Q[a][a2]   (controller.rs:96, M^T W4)
         const int r = p.r, fr = nrhs;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
     load(p.H, EH);
     lds_barrier();
 #pragma unroll
-    for (int j = 0; j < NR; ++j) a[j] = stage[(j * NR + ii) * ldi + gi];
+    for (int j = 0; j < NR; ++j) a[j] = stage[(p.transposed ? ii * NR + j : j * NR + ii) * ldi + gi];
     lds_barrier();
     load(p.R, ER);
     lds_barrier();
@@ -518,7 +522,8 @@ int launch_solve(const SolveArgs &a, hipStream_t s) {
     if (a.nrow == 4) return launch_tiny<4>(a, s);
     // the reference's horizon with rows in registers: gain of a single-output plant, and the solve
     if (a.nrow == 20 && a.nrhs == 20 && a.Q && a.r == 1 && a.R != a.X) return launch_rows<20, 20, 1>(a, s);
-    if (a.nrow == 20 && a.nrhs == 1 && !a.Q && a.R != a.X) return launch_rows<20, 1, 0>(a, s);
+    // (in place is fine here: a workgroup reads the right-hand sides of its own instances into LDS before it writes them)
+    if (a.nrow == 20 && a.nrhs == 1 && !a.Q) return launch_rows<20, 1, 0>(a, s);
     if (a.nrow <= 64) {
         const int rc = a.nrow <= 16 ? launch_small<16>(a, s) : a.nrow <= 32 ? launch_small<32>(a, s) : launch_small<64>(a, s);
         if (rc != MPCX_ERR_UNSUPPORTED) return rc;
@@ -547,7 +552,7 @@ bool solve_fits_on_chip(int nr, int nrhs) {
 
 int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *info, long long batch, long long W, int vm,
                     double *ws, size_t ws_doubles, hipStream_t s) {
-    SolveArgs a{H, fvec, u_seq, info, batch, W, vm, 1, 1, nullptr, 0};
+    SolveArgs a{H, fvec, u_seq, info, batch, W, vm, 1, 1, nullptr, 0, 0};
     const int rc = launch_solve(a, s);
     if (rc != MPCX_ERR_UNSUPPORTED) return rc;
     return launch_solve_large(H, fvec, nullptr, 0, u_seq, info, batch, W, vm, 1, 1, ws, ws_doubles, s);
@@ -555,11 +560,11 @@ int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *inf
 
 // X = H^-1 R with R handed over in X (overwritten in place), any size the solvers take.
 int launch_solve_inplace(const double *H, double *X, int *info, long long batch, long long W, int nr, int nrhs, double *ws,
-                         size_t ws_doubles, hipStream_t s) {
-    SolveArgs a{H, X, X, info, batch, W, nr, nrhs, 0, nullptr, 0};  // every kernel reads R completely before it writes X
+                         size_t ws_doubles, hipStream_t s, int transposed) {
+    SolveArgs a{H, X, X, info, batch, W, nr, nrhs, 0, nullptr, 0, transposed};  // every kernel reads R completely before it writes X
     const int rc = launch_solve(a, s);
     if (rc != MPCX_ERR_UNSUPPORTED) return rc;
-    return launch_solve_large(H, X, nullptr, 0, X, info, batch, W, nr, nrhs, 0, ws, ws_doubles, s);
+    return launch_solve_large(H, X, nullptr, 0, X, info, batch, W, nr, nrhs, 0, ws, ws_doubles, s, transposed);
 }
 
 namespace {
@@ -596,7 +601,7 @@ int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double
                    long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s) {
     const int nr = v * m, nrhs = f * r;
     if (nr <= 64) {  // small systems: Gamma^T W4 is formed while the workgroup loads its instances
-        SolveArgs a{H, Gamma, gain, info, batch, W, nr, nrhs, 0, Q, r};
+        SolveArgs a{H, Gamma, gain, info, batch, W, nr, nrhs, 0, Q, r, 0};
         const int rc = launch_solve(a, s);
         if (rc != MPCX_ERR_UNSUPPORTED) return rc;
     }
@@ -608,7 +613,7 @@ int launch_qp_gain(const double *H, const double *Gamma, const double *Q, double
         hipLaunchKernelGGL(gamma_t_q_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Gamma, Q, gain, batch, W, m, r, f, v);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
-        SolveArgs a{H, gain, gain, info, batch, W, nr, nrhs, 0, nullptr, 0};  // in place: R is read into LDS before X is written
+        SolveArgs a{H, gain, gain, info, batch, W, nr, nrhs, 0, nullptr, 0, 0};  // in place: R is read into LDS before X is written
         return launch_solve(a, s);
     }
     return launch_solve_large(H, Gamma, Q, r, gain, info, batch, W, nr, nrhs, 0, ws, ws_doubles, s);

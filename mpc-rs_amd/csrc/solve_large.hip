@@ -70,6 +70,7 @@ struct PackArgs {
     double *ws;
     long long first, count, W;  // instances [first, first + count) of the batch
     int nr, nrp;
+    int transposed;  // 1: the workspace receives H^T
 };
 
 // Lanes run along the rows of a column on both sides.
@@ -80,8 +81,25 @@ __global__ __launch_bounds__(256) void lu_pack_kernel(PackArgs p) {
     const long long li = idx / per, e = idx - li * per;
     const int col = (int)(e / p.nrp), row = (int)(e - (long long)col * p.nrp);
     const long long b = p.first + li;
-    p.ws[idx] = (row < p.nr && col < p.nr) ? p.H[elem_index(b, (long long)col * p.nr + row, (long long)p.nr * p.nr, p.W)]
-                                           : (row == col ? 1.0 : 0.0);
+    const long long src = p.transposed ? (long long)row * p.nr + col : (long long)col * p.nr + row;
+    p.ws[idx] = (row < p.nr && col < p.nr) ? p.H[elem_index(b, src, (long long)p.nr * p.nr, p.W)] : (row == col ? 1.0 : 0.0);
+}
+
+// The same with H^T for instance-major batches, through 16 x 16 LDS tiles so that both the reads of H (along its
+// columns) and the writes of the workspace (along its columns) are 128-byte runs.
+__global__ __launch_bounds__(256) void lu_pack_transposed_kernel(PackArgs p) {
+    __shared__ double tile[16][17];
+    const int tiles = p.nrp / 16;
+    const long long li = blockIdx.x / (tiles * tiles);
+    const int t = (int)(blockIdx.x - li * tiles * tiles), tr = t / tiles, tc = t - tr * tiles;  // tile of the workspace: rows tr, columns tc
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const double *H = p.H + (p.first + li) * (long long)p.nr * p.nr;
+    // workspace (row, col) = H(col, row): read H's column (tr * 16 + ty), rows tc * 16 + tx
+    const int hr = tc * 16 + tx, hc = tr * 16 + ty;
+    tile[ty][tx] = (hr < p.nr && hc < p.nr) ? H[(long long)hc * p.nr + hr] : (hr == hc ? 1.0 : 0.0);
+    __syncthreads();
+    const int row = tr * 16 + tx, col = tc * 16 + ty;
+    p.ws[(size_t)li * p.nrp * p.nrp + (size_t)col * p.nrp + row] = tile[tx][ty];
 }
 
 // ---- factor / eliminate: one workgroup per instance ----
@@ -723,7 +741,7 @@ bool solve_large_supports(int nr) {
 // R / Q as in the small kernels (Q != nullptr: R is Gamma and the right-hand side Gamma^T blockdiag(Q)).  `ws` holds
 // `ws_doubles` doubles; the batch is processed in as many launches as that takes.
 int launch_solve_large(const double *H, const double *R, const double *Q, int r, double *X, int *info, long long batch,
-                       long long W, int nr, int nrhs, int negate, double *ws, size_t ws_doubles, hipStream_t s) {
+                       long long W, int nr, int nrhs, int negate, double *ws, size_t ws_doubles, hipStream_t s, int transposed) {
     const int nrp = (nr + 15) & ~15;
     const size_t lds_bytes = lu_lds_bytes(nrp), rhs_bytes = rhs_lds_bytes(nrp);
     if (!solve_large_supports(nr)) return MPCX_ERR_UNSUPPORTED;
@@ -739,8 +757,12 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         if (e != hipSuccess) return (int)e;
         const long long pblocks = (count * (long long)nrp * nrp + 255) / 256;
         if (pblocks > 0x7fffffffLL || count > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-        PackArgs pa{H, ws, first, count, W, nr, nrp};
-        hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa);
+        PackArgs pa{H, ws, first, count, W, nr, nrp, transposed};
+        const long long tblocks = count * (long long)(nrp / 16) * (nrp / 16);
+        if (transposed && W == 1 && tblocks <= 0x7fffffffLL)
+            hipLaunchKernelGGL(lu_pack_transposed_kernel, dim3((unsigned)tblocks), dim3(256), 0, s, pa);
+        else
+            hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa);
         LuArgs la{ws, failed, count, nrp, meta};
         RhsArgs ra{ws, failed, meta, R, Q, X, info, first, count, W, 0, nr, nrhs, r, nrp, negate, rhs_ld(nrp)};
         if (left_looking(nrp)) {

@@ -29,6 +29,7 @@ EXPORTS = (
     "mpcx_version", "mpcx_array_elems", "mpcx_create", "mpcx_destroy", "mpcx_last_error", "mpcx_reserve", "mpcx_set_option",
     "mpcx_qp_build_f64", "mpcx_qp_build_f64_dev", "mpcx_rollout_f64", "mpcx_rollout_f64_dev",
     "mpcx_qp_solve_f64", "mpcx_qp_solve_f64_dev", "mpcx_qp_gain_f64", "mpcx_qp_gain_f64_dev",
+    "mpcx_qp_gain_rows_f64", "mpcx_qp_gain_rows_f64_dev",
     "mpcx_closed_loop_f64", "mpcx_closed_loop_f64_dev",
     "mpcx_c2d_backward_euler_f64", "mpcx_c2d_backward_euler_f64_dev", "mpcx_c2d_backward_euler_f64_noalloc_dev",
     "mpcx_plants_f64", "mpcx_plants_f64_dev",
@@ -107,6 +108,10 @@ def lib() -> C.CDLL:
     lb.mpcx_qp_gain_f64.restype = C.c_int
     lb.mpcx_qp_gain_f64_dev.argtypes = [vp, C.POINTER(Dims), dp, dp, dp, dp, vp, vp]
     lb.mpcx_qp_gain_f64_dev.restype = C.c_int
+    lb.mpcx_qp_gain_rows_f64.argtypes = [vp, C.POINTER(Dims), dp, dp, dp, dp, vp]
+    lb.mpcx_qp_gain_rows_f64.restype = C.c_int
+    lb.mpcx_qp_gain_rows_f64_dev.argtypes = [vp, C.POINTER(Dims), dp, dp, dp, dp, vp, vp]
+    lb.mpcx_qp_gain_rows_f64_dev.restype = C.c_int
     lb.mpcx_closed_loop_f64.argtypes = [vp, C.POINTER(Dims)] + [dp] * 10
     lb.mpcx_closed_loop_f64.restype = C.c_int
     lb.mpcx_closed_loop_f64_dev.argtypes = [vp, C.POINTER(Dims)] + [dp] * 10 + [vp]
@@ -318,6 +323,21 @@ class Context:
         info = np.full(max(batch, 1), -1, dtype=np.int32)
         self._check(self._lib.mpcx_qp_gain_f64(self._h, C.byref(d), _hp(hb), _hp(gb), _hp(qb), _hp(out), info.ctypes.data_as(C.c_void_p)))
         return L.unpack(out, batch, v * m, f * r, interleave), info[:batch]
+
+    def qp_gain_rows_dev(self, dims: Dims, H, Gamma, W4, gain_rows, info, stream=0):
+        self._check(self._lib.mpcx_qp_gain_rows_f64_dev(self._h, C.byref(dims), H, Gamma, W4, gain_rows, info, stream))
+
+    def qp_gain_rows(self, H, Gamma, Q, m, r, f, v, interleave=L.INTERLEAVE_AOS, weights_mode=WEIGHTS_BLOCK):
+        """The first m rows of the gain, (batch, m, fr), and info (batch,): what the control move uses
+        (controller.rs:130-132); pass it to closed_loop with v = 1."""
+        H = np.asarray(H, dtype=np.float64)
+        batch = H.shape[0]
+        d = make_dims(1, m, r, f, v, batch, 0, interleave, weights_mode)
+        hb, gb, qb = L.pack(H, interleave), L.pack(np.asarray(Gamma, dtype=np.float64), interleave), L.colmajor(Q)
+        out = np.full(max(L.array_elems(batch, interleave, m * f * r), 1), np.nan)
+        info = np.full(max(batch, 1), -1, dtype=np.int32)
+        self._check(self._lib.mpcx_qp_gain_rows_f64(self._h, C.byref(d), _hp(hb), _hp(gb), _hp(qb), _hp(out), info.ctypes.data_as(C.c_void_p)))
+        return L.unpack(out, batch, m, f * r, interleave), info[:batch]
 
     def c2d_dev(self, dims: Dims, Ac, Bc, dt, A, B, info, stream=0):
         self._check(self._lib.mpcx_c2d_backward_euler_f64_dev(self._h, C.byref(dims), Ac, Bc, dt, A, B, info, stream))

@@ -5,9 +5,9 @@ use std::path::PathBuf;
 use std::process::Command;
 
 // the SRCS list of mpc-rs_amd/csrc/Makefile, in its order (tests/test_host_cpu.py holds the two against each other)
-const SOURCES: [&str; 12] = [
+const SOURCES: [&str; 13] = [
     "mpcx_api.hip", "qp_lane.hip", "qp_wg.hip", "hessian_mfma.hip", "dense_w4.hip", "solve.hip", "solve_large.hip",
-    "plants.hip", "closed_loop.hip", "rollout.hip", "util.hip", "comm.hip",
+    "gain_rows.hip", "plants.hip", "closed_loop.hip", "rollout.hip", "util.hip", "comm.hip",
 ];
 
 fn main() {

@@ -92,6 +92,10 @@ extern "C" {
         w4: *const f64, gain: *mut f64, info: *mut i32) -> c_int;
     pub fn mpcx_qp_gain_f64_dev(ctx: *mut mpcx_ctx, dims: *const mpcx_dims, h: *const f64, gamma: *const f64,
         w4: *const f64, gain: *mut f64, info: *mut i32, stream: *mut c_void) -> c_int;
+    pub fn mpcx_qp_gain_rows_f64(ctx: *mut mpcx_ctx, dims: *const mpcx_dims, h: *const f64, gamma: *const f64,
+        w4: *const f64, gain_rows: *mut f64, info: *mut i32) -> c_int;
+    pub fn mpcx_qp_gain_rows_f64_dev(ctx: *mut mpcx_ctx, dims: *const mpcx_dims, h: *const f64, gamma: *const f64,
+        w4: *const f64, gain_rows: *mut f64, info: *mut i32, stream: *mut c_void) -> c_int;
 
     pub fn mpcx_closed_loop_f64(ctx: *mut mpcx_ctx, dims: *const mpcx_dims, a: *const f64, b: *const f64,
         c: *const f64, x0: *const f64, phi: *const f64, gain: *const f64, reference: *const f64, x: *mut f64,
