@@ -58,12 +58,29 @@ class mpc:  # noqa: N801  (module name in the reference)
                 raise RuntimeError("Matrix inversion failed")
             return mat_o, mat_m, gain[0]
 
+        @staticmethod
+        def form_first_move_rows(mat_a, mat_b, mat_c, f: int, v: int, mat_w3, mat_w4):
+            """(mat_o, rows) with rows = the first m rows of the gain matrix, which is all the control move uses
+            (controller.rs:130-132).  An addition: m solves with H^T instead of f r solves (mpcx_qp_gain_rows); raises
+            RuntimeError("Matrix inversion failed") where form_lifted_matrices does."""
+            mat_o, mat_m, h = mpc.Controller.lifted_and_hessian(mat_a, mat_b, mat_c, f, v, mat_w3, mat_w4)
+            mat_w4 = np.asarray(mat_w4, dtype=np.float64)
+            m, r = np.asarray(mat_b).shape[1], np.asarray(mat_c).shape[0]
+            q = _block_of(mat_w4, f, r)
+            mode, w4 = (ffi.WEIGHTS_BLOCK, q) if q is not None else (ffi.WEIGHTS_DENSE, mat_w4)
+            rows, info = context().qp_gain_rows(h[None], mat_m[None], w4, m, r, f, v, weights_mode=mode)
+            if info[0] != 0:
+                raise RuntimeError("Matrix inversion failed")
+            return mat_o, rows[0]
+
         @classmethod
         def new(cls, model: DiscreteStateSpaceModel, f: int, v: int, q0: float, q_other: float, pred_weight: float,
-                desired_ctrl_traj: np.ndarray, all_elements: bool = True) -> "mpc.Controller":
+                desired_ctrl_traj: np.ndarray, all_elements: bool = True, first_move_only: bool = False) -> "mpc.Controller":
             """controller.rs:137-207.  `all_elements` (an addition, default = the reference) keeps the reference's weight
             blocks, every element of an m x m / r x r block set to the weight (:164-165, :184); False builds q I blocks,
-            which is what a plant with several inputs or outputs needs for the Hessian to be invertible."""
+            which is what a plant with several inputs or outputs needs for the Hessian to be invertible.
+            `first_move_only` (an addition, default = the reference's full gain) keeps only the first m rows of the gain
+            matrix: every method of the controller reads no more than those."""
             m = model.get_mat_b().shape[1]
             r = model.get_mat_c().shape[0]
             w1 = np.zeros((v * m, v * m))  # :149-161
@@ -78,7 +95,10 @@ class mpc:  # noqa: N801  (module name in the reference)
             w4 = np.zeros((f * r, f * r))  # :179-185
             for i in range(f):
                 w4[i * r:(i + 1) * r, i * r:(i + 1) * r] = np.full((r, r), pred_weight) if all_elements else pred_weight * np.eye(r)
-            mat_o, _, gain = cls.form_lifted_matrices(model.get_mat_a(), model.get_mat_b(), model.get_mat_c(), f, v, w3, w4)
+            if first_move_only:
+                mat_o, gain = cls.form_first_move_rows(model.get_mat_a(), model.get_mat_b(), model.get_mat_c(), f, v, w3, w4)
+            else:
+                mat_o, _, gain = cls.form_lifted_matrices(model.get_mat_a(), model.get_mat_b(), model.get_mat_c(), f, v, w3, w4)
             return cls(model, f, mat_o, gain, np.array(desired_ctrl_traj, dtype=np.float64, copy=True))
 
         def propagate_dynamics(self, control_input: np.ndarray, state: np.ndarray):

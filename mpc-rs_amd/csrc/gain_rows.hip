@@ -40,10 +40,18 @@ __global__ __launch_bounds__(64) void rows_lane_kernel(const double *__restrict_
         for (int a2 = 0; a2 < r; ++a2)
             for (int i = 0; i < m; ++i) {
                 double acc = 0.0;
-                for (int k = 0; k < VM; ++k) {
-                    double t = 0.0;
-                    for (int a = 0; a < r; ++a) t += g[((long long)k * FR + blk * r + a) * W] * Q[a2 * r + a];
-                    acc += ylds[(i * VM + k) * 64 + tid] * t;
+                if (r == 1) {  // one load per term: keep several in flight
+                    const double q = Q[0];
+                    const double *gp = g + (long long)blk * W;
+#pragma unroll 8
+                    for (int k = 0; k < VM; ++k) acc += ylds[(i * VM + k) * 64 + tid] * (gp[(long long)k * FR * W] * q);
+                } else {
+#pragma unroll 2
+                    for (int k = 0; k < VM; ++k) {
+                        double t = 0.0;
+                        for (int a = 0; a < r; ++a) t += g[((long long)k * FR + blk * r + a) * W] * Q[a2 * r + a];
+                        acc += ylds[(i * VM + k) * 64 + tid] * t;
+                    }
                 }
                 out[((long long)(blk * r + a2) * m + i) * W] = acc;
             }

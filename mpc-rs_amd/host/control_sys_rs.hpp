@@ -388,6 +388,26 @@ class Controller {
         return {std::move(mat_o), std::move(mat_m), std::move(gain)};
     }
 
+    // Addition: (mat_o, rows) with rows = the first m rows of gain_matrix (m x f r), all that the control move uses
+    // (controller.rs:130-132): m solves with H^T instead of f r solves (mpcx_qp_gain_rows_f64).  Throws as above.
+    static std::pair<na::DMatrix, na::DMatrix> form_first_move_rows(const na::DMatrix &mat_a, const na::DMatrix &mat_b,
+                                                                    const na::DMatrix &mat_c, std::size_t f, std::size_t v,
+                                                                    const na::DMatrix &mat_w3, const na::DMatrix &mat_w4) {
+        na::DMatrix mat_o, mat_m, h;
+        mpcx_dims d;
+        lifted_and_hessian(mat_a, mat_b, mat_c, f, v, mat_w3, mat_w4, mat_o, mat_m, h, d);
+        const std::size_t r = mat_c.nrows(), m = mat_b.ncols();
+        na::DMatrix rows(m, f * r);
+        const na::DMatrix q = block_of(mat_w4, r);
+        const double *w4 = d.weights_mode == MPCX_WEIGHTS_BLOCK ? q.as_ptr() : mat_w4.as_ptr();
+        std::int32_t info = -1;
+        control_sys_rs::detail::Device::check(
+            mpcx_qp_gain_rows_f64(control_sys_rs::detail::Device::ctx(), &d, h.as_ptr(), mat_m.as_ptr(), w4, rows.as_mut_ptr(), &info),
+            "mpcx_qp_gain_rows_f64");
+        if (info != 0) throw Error("Matrix inversion failed");  // controller.rs:93-95
+        return {std::move(mat_o), std::move(rows)};
+    }
+
     // Addition: the matrix the reference hands to try_inverse, H = M^T W4 M + W3 (controller.rs:92-93), with O and M.
     static std::tuple<na::DMatrix, na::DMatrix, na::DMatrix> form_lifted_matrices_and_hessian(
         const na::DMatrix &mat_a, const na::DMatrix &mat_b, const na::DMatrix &mat_c, std::size_t f, std::size_t v,
@@ -400,9 +420,11 @@ class Controller {
 
     // controller.rs:137-207.  The weights are built on the host exactly as the reference builds them: every element of a
     // weight block is set to the weight (:164-165, :184).  `all_elements = false` (an addition) builds q I blocks, which
-    // a plant with several inputs or outputs needs for the Hessian to be invertible.
+    // a plant with several inputs or outputs needs for the Hessian to be invertible.  `first_move_only = true` (an
+    // addition) keeps only the first m rows of the gain matrix: no method of the controller reads more than those.
     static Controller new_(std::shared_ptr<const model::DiscreteStateSpaceModel> model, std::size_t f, std::size_t v, double q0,
-                           double q_other, double pred_weight, const na::DMatrix &desired_ctrl_traj, bool all_elements = true) {
+                           double q_other, double pred_weight, const na::DMatrix &desired_ctrl_traj, bool all_elements = true,
+                           bool first_move_only = false) {
         const std::size_t m = model->get_mat_b().ncols(), r = model->get_mat_c().nrows();
         const std::size_t vm = v * m;
         // W1 (:149-161) and W2 (:164-175)
@@ -433,14 +455,21 @@ class Controller {
         for (std::size_t i = 0; i < f; ++i)
             for (std::size_t a = 0; a < r; ++a)
                 for (std::size_t b = 0; b < r; ++b) w4(i * r + a, i * r + b) = (all_elements || a == b) ? pred_weight : 0.0;
-        auto omg = form_lifted_matrices(model->get_mat_a(), model->get_mat_b(), model->get_mat_c(), f, v, w3, w4);  // :190-198
         Controller c;
-        c.model_ = std::move(model);
         c.f_ = f;
-        c.v_ = v;
         c.desired_ctrl_traj_total = desired_ctrl_traj;
-        c.mat_o_ = std::move(std::get<0>(omg));
-        c.gain_matrix_ = std::move(std::get<2>(omg));
+        if (first_move_only) {
+            auto orows = form_first_move_rows(model->get_mat_a(), model->get_mat_b(), model->get_mat_c(), f, v, w3, w4);
+            c.v_ = 1;  // the stored gain is (1 m) x (f r)
+            c.mat_o_ = std::move(orows.first);
+            c.gain_matrix_ = std::move(orows.second);
+        } else {
+            auto omg = form_lifted_matrices(model->get_mat_a(), model->get_mat_b(), model->get_mat_c(), f, v, w3, w4);  // :190-198
+            c.v_ = v;
+            c.mat_o_ = std::move(std::get<0>(omg));
+            c.gain_matrix_ = std::move(std::get<2>(omg));
+        }
+        c.model_ = std::move(model);
         return c;
     }
 
@@ -623,6 +652,17 @@ inline std::pair<std::vector<double>, std::vector<std::int32_t>> gain_batched(co
     detail::Device::check(mpcx_qp_gain_f64(detail::Device::ctx(), &d, qp.h.data(), qp.gamma.data(), q.as_ptr(), gain.data(),
                                            info.data()), "mpcx_qp_gain_f64");
     return {std::move(gain), std::move(info)};
+}
+
+// The first m rows of every plant's gain (m x (f r) per plant): what the control move applies (controller.rs:130-132),
+// for the cost of the factorisation alone.  Same status array.
+inline std::pair<std::vector<double>, std::vector<std::int32_t>> gain_rows_batched(const QpBatch &qp, const na::DMatrix &q) {
+    std::vector<double> rows(qp.batch * qp.m * qp.f * qp.r);
+    std::vector<std::int32_t> info(qp.batch, -1);
+    const mpcx_dims d = detail::dims(qp.n, qp.m, qp.r, qp.f, qp.v, (std::int64_t)qp.batch);
+    detail::Device::check(mpcx_qp_gain_rows_f64(detail::Device::ctx(), &d, qp.h.data(), qp.gamma.data(), q.as_ptr(), rows.data(),
+                                                info.data()), "mpcx_qp_gain_rows_f64");
+    return {std::move(rows), std::move(info)};
 }
 
 }  // namespace batch

@@ -68,3 +68,15 @@ pub fn gain_batched(qp: &QpBatch, q: &na::DMatrix<f64>) -> (Vec<f64>, Vec<i32>) 
     });
     (gain, info)
 }
+
+/// The first m rows of every plant's gain (m x (f r) per plant, column-major): what the control move applies
+/// (controller.rs:130-132), for the cost of the factorisation alone (`mpcx_qp_gain_rows_f64`).  Same `info`.
+pub fn gain_rows_batched(qp: &QpBatch, q: &na::DMatrix<f64>) -> (Vec<f64>, Vec<i32>) {
+    let mut rows = vec![0.0; qp.batch * qp.m * qp.f * qp.r];
+    let mut info = vec![-1i32; qp.batch];
+    let d = dims(qp.n, qp.m, qp.r, qp.f, qp.v, qp.batch as i64, 0);
+    with_ctx("mpcx_qp_gain_rows_f64", |ctx| unsafe {
+        sys::mpcx_qp_gain_rows_f64(ctx, &d, qp.h.as_ptr(), qp.gamma.as_ptr(), q.as_ptr(), rows.as_mut_ptr(), info.as_mut_ptr())
+    });
+    (rows, info)
+}

@@ -77,6 +77,26 @@ pub mod mpc {
             Ok((mat_o, mat_m, gain_matrix))
         }
 
+        /// Addition: (mat_o, rows) with rows = the first m rows of gain_matrix (m x f r), all that the control move uses
+        /// (controller.rs:130-132): m solves with H^T instead of f r solves (`mpcx_qp_gain_rows_f64`).
+        pub fn form_first_move_rows(mat_a: &na::DMatrix<f64>, mat_b: &na::DMatrix<f64>, mat_c: &na::DMatrix<f64>, f: usize,
+                                    v: usize, mat_w3: &na::DMatrix<f64>, mat_w4: &na::DMatrix<f64>)
+                                    -> Result<(na::DMatrix<f64>, na::DMatrix<f64>), Box<dyn Error>> {
+            let (mat_o, mat_m, h, d) = lifted_and_hessian(mat_a, mat_b, mat_c, f, v, mat_w3, mat_w4);
+            let (r, m) = (mat_c.nrows(), mat_b.ncols());
+            let q = mat_w4.view((0, 0), (r, r)).into_owned();
+            let w4 = if d.weights_mode == sys::MPCX_WEIGHTS_BLOCK { q.as_ptr() } else { mat_w4.as_ptr() };
+            let mut rows = na::DMatrix::<f64>::zeros(m, f * r);
+            let mut info: i32 = -1;
+            with_ctx("mpcx_qp_gain_rows_f64", |ctx| unsafe {
+                sys::mpcx_qp_gain_rows_f64(ctx, &d, h.as_ptr(), mat_m.as_ptr(), w4, rows.as_mut_ptr(), &mut info)
+            });
+            if info != 0 {
+                return Err("Matrix inversion failed".into()); // controller.rs:93-95
+            }
+            Ok((mat_o, rows))
+        }
+
         /// controller.rs:101-115: (x_kp1, y_k) with y_k = C x_k.  One rollout step on the device.
         pub fn propagate_dynamics(&self, control_input: &na::DVector<f64>, state: &na::DVector<f64>)
                                   -> (na::DVector<f64>, na::DVector<f64>) {

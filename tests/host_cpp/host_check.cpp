@@ -72,6 +72,12 @@ int main() {
             put("loop_inputs", inputs, 1, steps); put("loop_outputs", outputs, 1, steps); put("loop_states", states, 2, steps + 1);
             auto [S, U, Y] = mpc.closed_loop(steps, na::DVector::zeros(2));
             put("loop1_states", S); put("loop1_inputs", U); put("loop1_outputs", Y);
+            // the same controller keeping only the first row of the gain (an addition): same loop, same single moves
+            auto lean = controller::mpc::Controller::new_(motor, 20, 20, 0.0000000011, 0.0001, 10.0, traj, true, true);
+            put("lean_gain", lean.gain_matrix());
+            auto [S2, U2, Y2] = lean.closed_loop(steps, na::DVector::zeros(2));
+            put("lean_states", S2); put("lean_inputs", U2); put("lean_outputs", Y2);
+            put("lean_u0", std::vector<double>{lean.compute_control_input(0, na::DVector::zeros(2))[0]}, 1, 1);
             try {
                 mpc.compute_control_input(281, x);  // 281 + 20 > 300: view_range panics (controller.rs:121)
                 std::printf("slice_panic 1 1 0\n");

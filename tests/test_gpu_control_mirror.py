@@ -56,6 +56,14 @@ def test_main_rs_scenario(ctx):
     assert_close(o2[None], O[None], "mat_o")
     assert_close(m2[None], M[None], "mat_m")
     assert_close(g2[None], G[None], "gain", tol=1e-8)
+    # first_move_only (an addition): the controller keeps row 0 of the gain and produces the same loop
+    lean = controller.mpc.Controller.new(mdl, f, v, 0.0000000011, 0.0001, 10.0, traj, first_move_only=True)
+    assert lean._gain_matrix.shape == (1, f)
+    assert_close(lean._gain_matrix[None], G[None, :1], "first gain row", tol=1e-8)
+    X2, U2, Y2 = lean.closed_loop(time_steps - f, np.zeros(2))
+    assert_close(U2, In[None], "closed-loop inputs from the first gain row", tol=1e-8)
+    assert_close(Y2, Out, "closed-loop outputs from the first gain row", tol=1e-8)
+    assert abs(lean.compute_control_input(0, np.zeros(2))[0] - In[0]) <= 1e-8 * abs(In[0])
 
 
 def test_error_behaviour(ctx):

@@ -94,6 +94,10 @@ def test_controller_scenario_of_the_reference_demo(host):
     assert _rel(host["loop_outputs"].reshape(-1), Out[0, 1:]) <= 1e-8                # outputs[t+1] = y_t (main.rs:63)
     assert _rel(host["loop1_outputs"], Out) <= 1e-8                                  # with outputs[0] = C x0 (main.rs:41)
     assert host["slice_panic"][0, 0] == 1
+    # the controller that keeps only the first gain row (first_move_only): row 0 of the gain, same loop, same first move
+    assert host["lean_gain"].shape == (1, 20) and _rel(host["lean_gain"], G[:1]) <= 1e-10 * np.linalg.cond(H)
+    assert _rel(host["lean_inputs"].reshape(-1), In) <= 1e-8 and _rel(host["lean_states"], S) <= 1e-8
+    assert _rel(host["lean_outputs"], Out) <= 1e-8 and abs(host["lean_u0"][0, 0] - In[0]) <= 1e-8 * abs(In[0])
 
 
 @pytest.mark.gpu
