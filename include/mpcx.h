@@ -111,6 +111,10 @@ int mpcx_reserve(mpcx_ctx *ctx, const mpcx_dims *dims);
 /* Context options.  MPCX_OPT_RELAY_CAP_BYTES: upper bound of the instance-major copy through which an interleaved batch
  * reaches the workgroup kernels (default 2 GiB; the batch goes through in chunks of that size). */
 #define MPCX_OPT_RELAY_CAP_BYTES 1
+/* MPCX_OPT_QP_STREAMING: 1 sends every instance-major build with block weights through the streaming form (Markov vectors
+ * in a device workspace, see mpcx_qp_build) whatever its size; 0 (default) only the shapes beyond the on-chip kernels.
+ * For testing and for comparing the two forms; results agree to rounding. */
+#define MPCX_OPT_QP_STREAMING 2
 int mpcx_set_option(mpcx_ctx *ctx, int option, int64_t value);
 
 /*
@@ -125,10 +129,19 @@ int mpcx_set_option(mpcx_ctx *ctx, int option, int64_t value);
  * Inputs per instance: A, B, C, x0 (n), ref (f r).  Shared: W3 (v m x v m dense), W4 (r x r block or dense
  * (f r) x (f r), per dims->weights_mode).  Any output pointer may be NULL: that output is neither computed
  * for its own sake nor stored.  x0 / ref may be NULL when fvec is NULL; W3 / W4 when H and fvec are NULL.
- * Every layout is accepted for every shape.  Plants of up to 6 states and 2 inputs / outputs are native in the
- * interleaved layouts (one lane per instance); larger ones, MPCX_WEIGHTS_DENSE and MPCX_HESSIAN_CONTRACT are native
- * in interleave = 1, and an interleaved batch then goes through an instance-major copy in device scratch that the
- * context owns (at most 2 GiB at a time; every output is moved three times).  Exact zeros of W3 are skipped: the
+ * Layouts: plants of up to 6 states and 3 inputs / outputs are native in the interleaved layouts (one lane per
+ * instance); larger ones, MPCX_WEIGHTS_DENSE and MPCX_HESSIAN_CONTRACT are native in interleave = 1, and an interleaved
+ * batch then goes through an instance-major copy in device scratch that the context owns (at most 2 GiB at a time; every
+ * output is moved three times).
+ * Sizes: with MPCX_WEIGHTS_BLOCK and MPCX_HESSIAN_AUTO / STRUCTURED there is no limit on f, v or the product sizes beyond
+ * memory.  Three kernel families serve them: one lane per instance while (f r m + max(f r, v m m)) * 512 bytes fit 160 KB
+ * of LDS; one workgroup per instance while the instance's working set fits LDS -- about
+ * 2 m r (2 f - v + 1) + max(n n + n m + r n + 2 n + r r + 2 f r + power tables, 2 (2 v + 1) m m) + (f > v ? 2 (v + 1) m m : 0)
+ * <= 20 480 doubles (exactly: n=12 m=4 r=12 up to f = v = 127; n=8 m=2 r=2 up to f = v = 852); and beyond that a streaming form that keeps the
+ * Markov vectors in a device workspace the context owns (4 m f r + 2 f r doubles per instance in flight, at most 8 GiB at a
+ * time, see mpcx_reserve), limited only by 2 n (m + r) + n + r m <= 20 480 doubles of recurrence state.  MPCX_WEIGHTS_DENSE
+ * and MPCX_HESSIAN_CONTRACT keep on-chip limits ((f r)(m + 1) resp. the Markov vectors in LDS) and return
+ * MPCX_ERR_UNSUPPORTED beyond them.  Exact zeros of W3 are skipped: the
  * band structure of W3 is measured on the device by each call (W3 as Controller::new builds it is block tridiagonal,
  * controller.rs:149-177).  The context's scratch is shared by all its calls: do not run two calls of one context
  * concurrently on different streams.

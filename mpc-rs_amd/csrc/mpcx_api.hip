@@ -21,9 +21,12 @@ struct mpcx_ctx {
     void *stat_scratch;  // partial records of the stats reduction + one result record
     void *relay;         // instance-major copy of a chunk of the batch (interleaved data on the workgroup kernels)
     size_t relay_bytes;
+    void *qp_ws;         // Markov vectors of the streaming build (shapes beyond the on-chip kernels)
+    size_t qp_ws_bytes;
     void *w3win;         // band structure of W3, measured on the device by every build call of the workgroup kernels
     size_t w3win_bytes;
     size_t relay_cap;    // MPCX_OPT_RELAY_CAP_BYTES
+    int force_stream;    // MPCX_OPT_QP_STREAMING
     char err[512];
 };
 
@@ -96,6 +99,24 @@ int ensure_work(mpcx_ctx *ctx, size_t bytes) {
     }
     HIP_TRY(ctx, hipMalloc(&ctx->work, bytes));
     ctx->work_bytes = bytes;
+    return MPCX_OK;
+}
+
+// Workspace of the streaming build: the whole batch when that is at most kQpWsCap, else as many instances as the cap
+// holds (the build then runs in several launches); never less than one instance.
+constexpr size_t kQpWsCap = (size_t)8 << 30;
+int ensure_qp_ws(mpcx_ctx *ctx, const QpArgs &a) {
+    const size_t per = qp_stream_ws_doubles(a) * sizeof(double);
+    size_t want = per * (size_t)a.batch;
+    if (want > kQpWsCap) want = (kQpWsCap / per ? kQpWsCap / per : 1) * per;
+    if (want <= ctx->qp_ws_bytes) return MPCX_OK;
+    if (ctx->qp_ws) {
+        HIP_TRY(ctx, hipFree(ctx->qp_ws));
+        ctx->qp_ws = nullptr;
+        ctx->qp_ws_bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->qp_ws, want));
+    ctx->qp_ws_bytes = want;
     return MPCX_OK;
 }
 
@@ -173,7 +194,10 @@ int mpcx_create(mpcx_ctx **out, int device_id) {
     ctx->w3win_bytes = 0;
     ctx->relay = nullptr;
     ctx->relay_bytes = 0;
+    ctx->qp_ws = nullptr;
+    ctx->qp_ws_bytes = 0;
     ctx->relay_cap = (size_t)2 << 30;
+    ctx->force_stream = 0;
     ctx->err[0] = 0;
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -212,6 +236,7 @@ void mpcx_destroy(mpcx_ctx *ctx) {
     if (ctx->stat_scratch) (void)hipFree(ctx->stat_scratch);
     if (ctx->w3win) (void)hipFree(ctx->w3win);
     if (ctx->relay) (void)hipFree(ctx->relay);
+    if (ctx->qp_ws) (void)hipFree(ctx->qp_ws);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -223,6 +248,11 @@ int mpcx_set_option(mpcx_ctx *ctx, int option, int64_t value) {
     if (option == MPCX_OPT_RELAY_CAP_BYTES) {
         if (value < 1) return fail(ctx, MPCX_ERR_DIMS, "MPCX_OPT_RELAY_CAP_BYTES must be >= 1");
         ctx->relay_cap = (size_t)value;
+        return MPCX_OK;
+    }
+    if (option == MPCX_OPT_QP_STREAMING) {
+        if (value != 0 && value != 1) return fail(ctx, MPCX_ERR_DIMS, "MPCX_OPT_QP_STREAMING must be 0 or 1");
+        ctx->force_stream = (int)value;
         return MPCX_OK;
     }
     return fail(ctx, MPCX_ERR_DIMS, "unknown option %d", option);
@@ -253,8 +283,13 @@ static int qp_build_core(mpcx_ctx *ctx, const mpcx_dims *d, QpArgs a, hipStream_
         a.H = nullptr;
         if (!a.Phi && !a.Gamma && !a.fvec) return MPCX_OK;
     }
-    rc = launch_qp_lane(a, s);
-    if (rc == MPCX_ERR_UNSUPPORTED) rc = launch_qp_wg(a, d->hessian_algo, s);
+    rc = (ctx->force_stream && qp_stream_takes(a)) ? MPCX_ERR_UNSUPPORTED : launch_qp_lane(a, s);
+    if (rc == MPCX_ERR_UNSUPPORTED && !(ctx->force_stream && qp_stream_takes(a))) rc = launch_qp_wg(a, d->hessian_algo, s);
+    if (rc == MPCX_ERR_UNSUPPORTED && qp_stream_takes(a)) {  // beyond the on-chip working set: the streaming form
+        const int wrc = ensure_qp_ws(ctx, a);
+        if (wrc != MPCX_OK) return wrc;
+        rc = launch_qp_stream(a, (double *)ctx->qp_ws, ctx->qp_ws_bytes / sizeof(double), s);
+    }
     if (rc == MPCX_ERR_LAYOUT)
         return fail(ctx, rc, "n=%d m=%d r=%d needs the workgroup kernels, which take instance-major data (interleave = 1)",
                     d->n, d->m, d->r);
@@ -360,6 +395,19 @@ int mpcx_reserve(mpcx_ctx *ctx, const mpcx_dims *d) {
         const size_t need = (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n) * sizeof(double);
         if ((rc = ensure_aux(ctx, need)) != MPCX_OK) return rc;
     }
+    {  // shapes beyond the on-chip build kernels: the streaming build's workspace
+        QpArgs w = a;
+        w.W = 1;
+        double dummy = 0.0;
+        w.H = &dummy;  // (sizes do not depend on which outputs are asked for)
+        if (!qp_lane_takes(a) && !qp_wg_takes(w) && qp_stream_takes(w)) {
+            if (W != 1) {  // reached through the instance-major copy, a chunk at a time: bound the chunk by the inputs alone
+                const long long n = d->n, m = d->m, r = d->r;
+                w.batch = relay_chunk(ctx, n * n + n * m + r * n, d->batch);
+            }
+            if ((rc = ensure_qp_ws(ctx, w)) != MPCX_OK) return rc;
+        }
+    }
     if (W != 1 && (!qp_lane_takes(a) || d->hessian_algo == MPCX_HESSIAN_CONTRACT)) {  // instance-major copy of a build
         const long long n = d->n, m = d->m, r = d->r, FR = (long long)d->f * r, VM = (long long)d->v * m;
         const long long per = n * n + n * m + r * n + n + FR + FR * n + FR * VM + VM * VM + VM;
@@ -409,7 +457,7 @@ int mpcx_qp_build_f64_dev(mpcx_ctx *ctx, const mpcx_dims *d, const double *A, co
         a.w3win_bytes = ctx->w3win_bytes;
     }
     // only the one-lane-per-instance kernels read and write interleaved batches directly
-    const bool lane_all = qp_lane_takes(a) && !(H && d->hessian_algo == MPCX_HESSIAN_CONTRACT);
+    const bool lane_all = qp_lane_takes(a) && !(H && d->hessian_algo == MPCX_HESSIAN_CONTRACT) && !ctx->force_stream;
     if (W != 1 && !lane_all) return qp_build_relayed(ctx, d, a, s);
     return qp_build_core(ctx, d, a, s);
 }

@@ -46,6 +46,12 @@ struct LoopArgs {
 // what that kernel family holds on chip (the caller then tries the next family).
 int launch_qp_lane(const QpArgs &a, hipStream_t s);
 int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s);
+// The same build without an on-chip size limit (block weights, instance-major): Markov vectors in a device workspace of
+// qp_stream_ws_doubles(a) doubles per instance (fewer instances' worth means more launches).
+bool qp_wg_takes(const QpArgs &a);
+bool qp_stream_takes(const QpArgs &a);
+size_t qp_stream_ws_doubles(const QpArgs &a);
+int launch_qp_stream(const QpArgs &a, double *ws, size_t ws_doubles, hipStream_t s);
 int launch_hessian_mfma(const QpArgs &a, hipStream_t s);
 int launch_qp_dense(const QpArgs &a, hipStream_t s);
 // ws / ws_doubles: device workspace for systems beyond 64 unknowns (solve_large_ws_doubles per instance; fewer

@@ -1186,15 +1186,23 @@ int launch_wg_k(const QpArgs &a, size_t lds_bytes, hipStream_t s) {
 
 }  // namespace
 
+// True when an instance's working set (wg_lds_layout) fits the 160 KB of LDS and the index ranges of the kernel.
+bool qp_wg_takes(const QpArgs &a) {
+    if (a.weights_mode != MPCX_WEIGHTS_BLOCK && (a.H || a.fvec)) return false;
+    // (the plan's offsets are ints: sizes far beyond LDS must not reach it)
+    const double rough = 2.0 * a.m * a.f * a.r + 2.0 * a.v * a.m * a.m + (double)a.n * a.n;
+    if (rough > 1e6) return false;
+    const WgLds L = wg_lds_layout(a.n, a.m, a.r, a.f, a.v);
+    if ((size_t)L.total * sizeof(double) > 160 * 1024) return false;
+    return (long long)a.f * a.r * a.v * a.m <= 0x7fffffffLL && a.batch <= 0x7fffffffLL;
+}
+
 int launch_qp_wg(const QpArgs &a, int hessian_algo, hipStream_t s) {
     (void)hessian_algo;
     if (a.W != 1) return MPCX_ERR_LAYOUT;
-    if (a.weights_mode != MPCX_WEIGHTS_BLOCK && (a.H || a.fvec)) return MPCX_ERR_UNSUPPORTED;
+    if (!qp_wg_takes(a)) return MPCX_ERR_UNSUPPORTED;
     const WgLds L = wg_lds_layout(a.n, a.m, a.r, a.f, a.v);
     const size_t lds_bytes = (size_t)L.total * sizeof(double);
-    if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
-    if ((long long)a.f * a.r * a.v * a.m > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-    if (a.batch > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     // reach of W3's non-zeros around the block diagonal, for the sweep's loader waves (only where they move 16-byte pairs)
     QpArgs b = a;
     b.cu_count = 0;

@@ -23,6 +23,7 @@ WEIGHTS_BLOCK, WEIGHTS_DENSE = 0, 1
 HESSIAN_AUTO, HESSIAN_CONTRACT, HESSIAN_STRUCTURED = 0, 1, 2
 PLANT_DC_MOTOR, PLANT_TWO_MASS = 0, 1
 OPT_RELAY_CAP_BYTES = 1
+OPT_QP_STREAMING = 2
 
 # every symbol include/mpcx.h declares
 EXPORTS = (

@@ -5,8 +5,8 @@ use std::path::PathBuf;
 use std::process::Command;
 
 // the SRCS list of mpc-rs_amd/csrc/Makefile, in its order (tests/test_host_cpu.py holds the two against each other)
-const SOURCES: [&str; 13] = [
-    "mpcx_api.hip", "qp_lane.hip", "qp_wg.hip", "hessian_mfma.hip", "dense_w4.hip", "solve.hip", "solve_large.hip",
+const SOURCES: [&str; 14] = [
+    "mpcx_api.hip", "qp_lane.hip", "qp_wg.hip", "qp_stream.hip", "hessian_mfma.hip", "dense_w4.hip", "solve.hip", "solve_large.hip",
     "gain_rows.hip", "plants.hip", "closed_loop.hip", "rollout.hip", "util.hip", "comm.hip",
 ];
 
