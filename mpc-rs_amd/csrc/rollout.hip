@@ -99,6 +99,11 @@ static_assert(kChunk % 8 == 0, "MPCX_RO_CHUNK must be a multiple of 8 (whole 128
 // LDS doubles per instance, kept even (16-byte aligned pairs).  (Staggering the instances of a wavefront over the LDS
 // banks by padding was measured: no gain, and the extra bytes cost resident wavefronts.)
 __host__ __device__ constexpr int pad_instance(int doubles) { return (doubles + 1) & ~1; }
+__host__ __device__ constexpr int ring_size(int need) {
+    int s = 64;
+    while (s < need) s *= 2;
+    return s;
+}
 
 // HX / HY: X / Y is stored.  Every chunk issues exactly kChunk stores per output, whatever the lane, the group or the
 // step: lanes beyond the last row repeat row 0's store, groups beyond the batch repeat the last instance's stores and
@@ -132,8 +137,7 @@ __device__ __forceinline__ void wave_lds_order() {
 // beyond the flush's end are not stored, and a pair with one live entry becomes an 8-byte store.
 __device__ __forceinline__ void flush_pair_masked(double *row, const double *ring, int a, int f, int RS, int lo, int hi, int end) {
     typedef double v2d __attribute__((ext_vector_type(2)));
-    f = f >= RS ? f - RS : f;
-    if (f >= RS) f -= RS;
+    f &= RS - 1;  // the ring size is a power of two
     const bool in0 = a >= lo && a < end && a < hi;
     const bool in1 = a + 1 >= lo && a + 1 < end && a + 1 < hi;
     if (in0 && in1) *(v2d *)(row + a) = *(const v2d *)(ring + f);
@@ -156,7 +160,11 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
     constexpr int SU = (SHU && G <= 32) ? 0 : ((G <= 32) ? MB : G);  // inputs kept per step (none: shared inputs come through scalar loads)
     const int mats = kRegs ? 0 : n * n + n * m + r * n;
     // staging of a chunk's outputs: two rings of RS doubles (X, Y) for the line-aligned paired flush, else [step][2][G]
-    constexpr int RS = kChunk * NP + 16;  // a full chunk plus the part of a line that waits for the next flush
+    // Ring of a row's stream: a full chunk, the part of a line that waits for the next flush, and the G - 1 entries
+    // beyond a step's rows that the surplus lanes of a group overwrite (see the step), rounded up to a power of two so
+    // that a position wraps with one AND (the step loop is bound by instruction issue: every integer instruction of the
+    // addressing costs as much as a multiply-add).
+    constexpr int RS = ring_size(kChunk * NP + 16 + G);
     const int stage = FF ? 2 * RS : kChunk * 2 * G;
     const int per_inst = pad_instance(mats + 2 * G + kChunk * SU + stage);
     double *sA = lds + (size_t)g * per_inst, *sB = sA + (kRegs ? 0 : n * n), *sC = sB + (kRegs ? 0 : n * m);
@@ -225,7 +233,10 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
         const int steps = (int)((T - t0 < kChunk) ? T - t0 : kChunk);
         // (FF) aligned coordinates of the first entries this chunk produces, and their ring positions
         const int prodx = ((int)t0 + 1) * n + misx, prody = (int)t0 * r + misy;
-        const int wx = prodx % RS, wy = prody % RS;
+        int cx = prodx + i, cy = prody + i;  // this lane's entry of step 0, unwrapped
+        // (opaque to the optimiser: otherwise it re-associates cx + q n into chunk-invariant per-step lane offsets, sixteen
+        // more live registers, and the step loop spills)
+        asm volatile("" : "+v"(cx), "+v"(cy));
         RSTAMP(0);
         if constexpr (!SHU) {
 #pragma unroll
@@ -265,6 +276,10 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
             }
             bu[q] = qv;
         }
+        // (pinned: left to itself the compiler sinks each product into its step, and the step then waits for the scalar
+        // loads of the inputs on the counter its state reads use)
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) asm volatile("" : "+v"(bu[q]));
         RSTAMP(2);
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
@@ -311,12 +326,12 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
             // rows at and beyond n (r) carry zero coefficients, so every lane writes: no divergence inside the step
             xn[i] = s;
             if constexpr (FF) {
-                // ring position of this step's entries (a single wrap: the offsets stay below the ring size)
-                int px = wx + q * n + i, py = wy + q * r + i;
-                px = px >= RS ? px - RS : px;
-                py = py >= RS ? py - RS : py;
-                if (i < n) sOut[px] = s;
-                if (i < r) sOut[RS + py] = y;
+                // Every lane stores: the lanes beyond row n - 1 (r - 1) carry zero coefficients and write zeros over the
+                // positions of the next step's first rows, which that step (later in this wavefront's program order)
+                // overwrites; past the last step of a chunk they land in the ring's spare entries, which are never flushed
+                // before the next chunk has written them.  No branch and no compare inside the step.
+                sOut[(cx + q * n) & (RS - 1)] = s;
+                sOut[RS + ((cy + q * r) & (RS - 1))] = y;
             } else {
                 out[i] = s;
                 out[G + i] = y;
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
             const bool last = t0 + steps >= T;
             const bool edge = last || t0 == 0;  // wave-uniform
             const int ax = prodx & ~15, ay = prody & ~15;  // first unflushed line of each row
-            const int fx = ax % RS, fy = ay % RS;
+            const int fx = ax & (RS - 1), fy = ay & (RS - 1);
             if (edge) {
                 constexpr int NSTE = (kChunk * NP + 16 + 2 * G - 1) / (2 * G);  // one more line than a full chunk
                 const int endx = (int)EX + misx, endy = (int)EY + misy;
@@ -352,9 +367,7 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
 #pragma unroll
                 for (int k = 0; k < NST; ++k) {
                     const int e2 = 2 * (i + k * G);
-                    int f = fx + e2, h = fy + e2;
-                    f = f >= RS ? f - RS : f;
-                    h = h >= RS ? h - RS : h;
+                    const int f = (fx + e2) & (RS - 1), h = (fy + e2) & (RS - 1);
                     if (HX) vx[k] = *(const v2d *)(sOut + (e2 < kChunk * n ? f : 0));
                     if (HY) vy[k] = *(const v2d *)(sOut + RS + (e2 < kChunk * r ? h : 0));
                 }
@@ -396,7 +409,7 @@ int launch_group_inst(const RolloutArgs &a, hipStream_t s) {
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     const size_t mats = G <= 32 ? 0 : (size_t)a.n * a.n + (size_t)a.n * a.m + (size_t)a.r * a.n;
     const size_t su = (SHU && G <= 32) ? 0 : (G <= 32 ? MB : G);
-    const size_t stage = FF ? (size_t)2 * (kChunk * NP + 16) : (size_t)kChunk * 2 * G;
+    const size_t stage = FF ? (size_t)2 * ring_size(kChunk * NP + 16 + G) : (size_t)kChunk * 2 * G;
     const size_t per_inst = (size_t)pad_instance((int)(mats + 2 * G + (size_t)kChunk * su + stage));
     const size_t lds_bytes = per_inst * IPW * sizeof(double);
     if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
