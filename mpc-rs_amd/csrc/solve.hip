@@ -333,16 +333,22 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
     const long long b0 = (long long)blockIdx.x * ipb;
     const int live = (p.batch - b0 < ipb) ? (int)(p.batch - b0) : ipb;
 
-    auto load = [&](const double *src, int E) {
+    // tr: the square matrix is staged transposed (element (row, col) lands where (col, row) would), so that the lanes'
+    // reads of their rows below are the same conflict-free pattern either way
+    auto load = [&](const double *src, int E, bool tr) {
         if (p.W > 1) {  // instance fastest
             const int step = nthreads / ipb, inst = tid % ipb;
             const double *sp = src + elem_index(b0 + (inst < live ? inst : 0), 0, E, p.W);
             if (inst < live)
-                for (int e = tid / ipb; e < E; e += step) stage[e * ldi + inst] = sp[(long long)e * p.W];
+                for (int e = tid / ipb; e < E; e += step) {
+                    const int es = tr ? (e % NR) * NR + e / NR : e;
+                    stage[es * ldi + inst] = sp[(long long)e * p.W];
+                }
         } else {        // instance-major: elements fastest
             for (int t = tid; t < live * E; t += nthreads) {
                 const int inst = t / E, e = t - inst * E;
-                stage[e * ldi + inst] = src[(b0 + inst) * (long long)E + e];
+                const int es = tr ? (e % NR) * NR + e / NR : e;
+                stage[es * ldi + inst] = src[(b0 + inst) * (long long)E + e];
             }
         }
     };
@@ -351,12 +357,12 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
     const int gi = g < ipb ? g : 0, ii = i < NR ? i : 0;
     double a[NC];
 
-    load(p.H, EH);
+    load(p.H, EH, p.transposed != 0);
     lds_barrier();
 #pragma unroll
-    for (int j = 0; j < NR; ++j) a[j] = stage[(p.transposed ? ii * NR + j : j * NR + ii) * ldi + gi];
+    for (int j = 0; j < NR; ++j) a[j] = stage[(j * NR + ii) * ldi + gi];
     lds_barrier();
-    load(p.R, ER);
+    load(p.R, ER, false);
     lds_barrier();
     if constexpr (RR == 0) {
 #pragma unroll
