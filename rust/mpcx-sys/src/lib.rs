@@ -25,6 +25,7 @@ pub const MPCX_HESSIAN_STRUCTURED: i32 = 2;
 pub const MPCX_PLANT_DC_MOTOR: c_int = 0;
 pub const MPCX_PLANT_TWO_MASS: c_int = 1;
 pub const MPCX_OPT_RELAY_CAP_BYTES: c_int = 1;
+pub const MPCX_OPT_QP_STREAMING: c_int = 2;
 
 #[repr(C)]
 pub struct mpcx_ctx {
