@@ -1,5 +1,6 @@
 """Phase stamps of the workgroup QP kernel (needs a library built with -DMPCX_WG_STAMPS, e.g. tools/build_variant.sh stamps qp_wg.hip -DMPCX_WG_STAMPS, and MPCX_LIB pointing at it; diagnostic, GPU only).
 With STAMPS2=1 in the environment and a -DMPCX_WG_STAMPS2 build: fvec is computed and the first loader wave's stamps around fvec and the held-input sums are printed (pass an output list without Phi: the stamps live in its buffer).
+With TIMELINE=1: mean time of each stamp since the kernel start per 256 consecutive workgroups.
 With PER_XCD=1: mean start, end and duration of the workgroups of each XCD (workgroup i runs on XCD i % 8)."""
 import os, sys
 import numpy as np, torch
@@ -39,6 +40,11 @@ for half in (0, 1):
     sel = dt[mid][half::2]
     print(("even" if half == 0 else "odd ") + " blocks: " + "  ".join(f"{nm} {x:6.1f}" for nm, x in zip(names, sel.mean(axis=0))) + f"  total {(st[mid][half::2, 9] - st[mid][half::2, 0]).mean() / 100:.1f} us")
 print("kernel span %.3f ms" % ((st[:, 9].max() - st[:, 0].min()) / 1e5))
+if os.environ.get("TIMELINE"):  # mean time of every stamp since the kernel's start, per group of 256 consecutive workgroups
+    t0 = st[:, 0].min()
+    for g0 in range(0, count, 256):
+        sel = (st[g0:g0 + 256] - t0) / 100.0
+        print(f"blocks {g0:5d}+: " + "  ".join(f"s{k} {np.nanmean(sel[:, k]):7.1f}" for k in (0, 1, 2, 3, 4, 6, 8, 9)))
 if os.environ.get("PER_XCD"):  # workgroup i runs on XCD i % 8: mean start, end and duration per XCD and dispatch round
     t0 = st[:, 0].min()
     for x in range(8):
