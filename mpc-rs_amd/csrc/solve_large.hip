@@ -421,19 +421,19 @@ constexpr int kMaxWeightBlock = 64;  // widest output weight block r served
 // modulo 32, so that the two groups served together use disjoint banks.
 int rhs_ld(int nrp) { return (nrp % 32 == 0) ? nrp + 16 : nrp; }
 
-// THREADS: workgroup size (>= 256); MT: row tiles per wavefront (THREADS / 64 * MT * 16 >= nrp); DB: the next panel's
-// multipliers are fetched while the current panel is applied (twice the registers).
+// THREADS: workgroup size (>= 256); MT: row tiles per wavefront (THREADS / 64 * MT * 16 >= nrp).
 //
 // FACTOR: the same machinery run over H's own column blocks, left-looking, one workgroup per instance: block j is
 // loaded, the panels 0..j-1 are applied to it exactly as to a block of right-hand sides, then it is factored in LDS as
 // panel j (pivot search, exchanges, multipliers for every row outside the pivot block) and written back with what the
 // later blocks need.  H's columns are read and written once; what is streamed per block are the multipliers of the
 // panels before it, half the bytes of a right-looking sweep over the trailing columns and reads only.
-template <int THREADS, int MT, bool DB, bool FACTOR>
+template <int THREADS, int MT, bool FACTOR>
 __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kernel(RhsArgs p) {  // at most 16 wavefronts (LDS slots)
     extern __shared__ __align__(16) double sm[];
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);  // the same number in a scalar register: conditions on it are branches, not masks
     const int nrp = p.nrp, ld = p.ld, npan = nrp / kNB, nblk = (p.nrhs + kNB - 1) / kNB;
     // Workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (instance, block) pairs, so
     // that the blocks of one instance, which read the same multipliers, share one L2.
@@ -461,25 +461,35 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
     const int kq = lane >> 4, l15 = lane & 15;
     const int lofs = kq * nrp + l15;  // a lane's place in a tile of multipliers: + panel's first column, + 4 q columns, + r0
     double *meta = p.meta + (size_t)li * npan * kMetaDoubles;
-    double lb[DB ? 2 : 1][MT][4];
-    auto fetch_multipliers = [&](int pn, double(&dst)[MT][4]) __attribute__((always_inline)) {
+    double lb[MT][4];
+    // The multipliers of a wavefront's tiles live in ONE set of registers: right after a tile's products have used them,
+    // the same registers are requested for the next panel, so the requests trickle into the memory pipeline between the
+    // products of a whole step instead of queueing up in front of it (36 requests in a row kept a wavefront 1-2 us at the
+    // queue's door), and each has a whole step to arrive.  Every load is issued unconditionally (a tile slot past the last
+    // tile, or the panel's own tile, reads the last tile / itself and the value is dropped): with a fixed number of loads
+    // per step the compiler can wait for "all but the loads issued since" when a multiplier is first used; behind a
+    // condition it cannot, and waits for every outstanding load.
+    auto fetch_tile = [&](int pn, int u, double(&dst)[4]) __attribute__((always_inline)) {
+        const int t0 = wvs + NW * u, t = t0 < npan ? t0 : npan - 1;
 #pragma unroll
-        for (int u = 0; u < MT; ++u) {
-            const int t = wv + NW * u;
-            if (t < npan && t != pn && !((MPCX_RHS_ABLATE & 64) && pn > 0)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    dst[u][q] = A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
-            }
-        }
+        for (int q = 0; q < 4; ++q) dst[q] = A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
     };
-    // what a thread carries of a panel's description: one entry of L11^-1 and one int of the exchange lists
+    // A panel's description is fetched one panel ahead: L11^-1 one entry per thread (it reaches the first wavefront
+    // through LDS), and in the first wavefront the rows the 16 pivot rows come from, in the layout its
+    // matrix-core product wants ([k = (lane >> 4) + 4 q]), and of the displaced rows the one this lane moves (entry
+    // 16 + (lane & 15) of the lists).
     double m_linv = 0.0;
-    int m_int = 0;
+    int m_ts[4] = {0, 0, 0, 0}, m_mvs = 0, m_mvd = 0, m_nt = 0;
     auto fetch_meta = [&](int pn) {
         const double *mt = meta + (size_t)pn * kMetaDoubles;
         if (tid < kNB * kNB) m_linv = mt[tid];
-        if (tid < 1 + 2 * kMaxTouched) m_int = ((const int *)(mt + kMetaInts))[tid];
+        if (wv != 0) return;
+        const int *mi = (const int *)(mt + kMetaInts);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m_ts[q] = mi[1 + kMaxTouched + kq + 4 * q];
+        m_nt = mi[0];
+        m_mvd = mi[1 + kNB + l15];
+        m_mvs = mi[1 + kMaxTouched + kNB + l15];
     };
     // The block: 16 columns of the right-hand side, rows beyond nr and columns beyond nrhs zero.
     if (FACTOR || (MPCX_RHS_ABLATE & 1)) {
@@ -526,74 +536,94 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
         }
         __syncthreads();  // the weight block leaves the U12 buffer
     }
-    auto panel_step = [&](int pn, int upto, double(&cur)[MT][4], double(&nxt)[MT][4]) __attribute__((always_inline)) {
+    // Diagnostic build (-DMPCX_RHS_STAMPS, tools/probe_rhs.py): lane 0 of every wavefront adds up, over the panels, the time
+    // it spends waiting at the step's first barrier, in the first wavefront's section and the requests, at the second
+    // barrier and in the tile updates; block 0 of every instance leaves the sums at the start of its instance's X.
+#ifdef MPCX_RHS_STAMPS
+    long long rs_last = 0;
+    double rs_sum[4] = {0.0, 0.0, 0.0, 0.0};
+#define RSTAMP(k) do { const long long now_ = wall_clock64(); if ((k) > 0) rs_sum[(k) - 1] += (double)(now_ - rs_last); rs_last = now_; } while (0)
+#else
+#define RSTAMP(k) do {} while (0)
+#endif
+    auto panel_step = [&](int pn, int upto) __attribute__((always_inline)) {
         if ((MPCX_RHS_ABLATE & 2) && pn >= 0) return;
         // (The barriers of a step order LDS traffic only: a __syncthreads() would also wait for the multipliers that were
         // just requested for the next panel.)
         const int k0 = pn * kNB;
+        RSTAMP(0);
         if (tid < kNB * kNB) linv[tid] = m_linv;
-        if (tid < 1 + 2 * kMaxTouched) tmeta[tid] = m_int;
-        lds_barrier();  // also orders the previous panel's updates (and the initial load) before the reads below
-        if (pn + 1 < upto) {
-            fetch_meta(pn + 1);
-            if (DB) fetch_multipliers(pn + 1, nxt);
+        lds_barrier();  // the previous panel's updates (and the initial load) are in place
+        RSTAMP(1);
+        // The first wavefront alone: the 16 pivot rows, read where they lie before the panel's exchanges, give
+        // U12 = L11^-1 T as one 16x16x16 product; the displaced rows are carried over.  Every read precedes every write
+        // within the wavefront (LDS operations of a wavefront execute in order), so the exchange needs no barrier.
+        // The requests for the next panel go out after it: nothing on this path waits for a load it has just issued.
+        if (wv == 0 && !(MPCX_RHS_ABLATE & 32)) {
+            double la[4], tb[4], mv[4];
+            const int mvs = m_mvs, mvd = m_mvd;
+            const bool moves = kNB + l15 < m_nt;
+            // (lane indices the compiler cannot see through: the addresses below are formed here, in a few instructions,
+            // instead of being kept in twenty registers across the whole panel loop)
+            int li = l15, ki = kq;
+            asm volatile("" : "+v"(li), "+v"(ki));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                la[q] = linv[li * kNB + ki + 4 * q];           // A operand: L11^-1[i = l15][k = kq + 4 q]
+                tb[q] = blk[li * ld + m_ts[q]];                // B operand: T[k = kq + 4 q][column l15]
+            }
+            d4 u12 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u12 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], tb[q], u12, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mv[q] = blk[(ki + 4 * q) * ld + (moves ? mvs : 0)];  // row mvs, column kq + 4 q
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // D[i = kq + 4 q][column l15]
+                blk[li * ld + k0 + ki + 4 * q] = u12[q];
+                u12s[(ki + 4 * q) * kNB + li] = u12[q];
+                if (moves) blk[(ki + 4 * q) * ld + mvd] = mv[q];
+            }
         }
-        // Rows after the panel's exchanges, read where they lie before them: the 16 pivot rows feed U12 = L11^-1 T,
-        // the displaced rows (entries 16.. of the list) are carried over.
-        const int ntouched = tmeta[0];
-        double uv = 0.0, moved = 0.0;
-        const int i = tid & 15, c = (tid >> 4) & 15;
-        if (tid < kNB * kNB && !(MPCX_RHS_ABLATE & 32)) {
-#pragma unroll 4
-            for (int k = 0; k < kNB; ++k) uv = fma(linv[i * kNB + k], blk[c * ld + tmeta[1 + kMaxTouched + k]], uv);
-            if (kNB + i < ntouched) moved = blk[(size_t)c * ld + tmeta[1 + kMaxTouched + kNB + i]];
-        }
+        const int pf = pn + 1 < upto ? pn + 1 : pn;  // the panel to request (after the last one: itself again, unused)
+        fetch_meta(pf);
+        RSTAMP(2);
         lds_barrier();
-        if (tid < kNB * kNB) {
-            blk[(size_t)c * ld + k0 + i] = uv;
-            u12s[i * kNB + c] = uv;
-            if (kNB + i < ntouched) blk[(size_t)c * ld + tmeta[1 + kNB + i]] = moved;
-        }
-        lds_barrier();
+        RSTAMP(3);
         d4 nu;
 #pragma unroll
         for (int q = 0; q < 4; ++q) nu[q] = -u12s[(kq + 4 * q) * kNB + l15];
         const int cofs = kq * ld + l15;  // + 4 q columns, + r0
+        // Straight-line code, the same for every tile slot: a slot past the last tile, or the panel's own tile, works on
+        // the last tile / on itself and does not write the result back.  Every tile of the wavefront is read before the
+        // first product (one LDS round trip per step, not one per tile).
+        d4 acc[MT];
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            const int t = wv + NW * u;
-            if (t < npan && t != pn && !(MPCX_RHS_ABLATE & 4)) {
-                const int r0 = t * kNB;
-                d4 acc;
+            const int t0 = wvs + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = blk[cofs + 4 * q * ld + r0];
+            for (int q = 0; q < 4; ++q) acc[u][q] = blk[cofs + 4 * q * ld + r0];
+        }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], cur[u][q], acc, 0, 0, 0);
+        for (int u = 0; u < MT; ++u) {
+            const int t0 = wvs + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
+            const bool live = t0 < npan && t0 != pn && !(MPCX_RHS_ABLATE & 4);  // uniform over the wavefront
 #pragma unroll
-                for (int q = 0; q < 4; ++q) blk[cofs + 4 * q * ld + r0] = acc[q];
+            for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb[u][q], acc[u], 0, 0, 0);
+            fetch_tile(pf, u, lb[u]);
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) blk[cofs + 4 * q * ld + r0] = acc[u][q];
             }
         }
-        if (!DB && pn + 1 < upto) fetch_multipliers(pn + 1, cur);
+        RSTAMP(4);
     };
     // the panels [0, upto) applied to the block in LDS
     auto apply_panels = [&](int upto) __attribute__((always_inline)) {
         if (upto <= 0) return;
-#pragma unroll
-        for (int u = 0; u < MT; ++u)  // every slot defined here: nothing of the previous block's multipliers stays live
-#pragma unroll
-            for (int q = 0; q < 4; ++q) lb[0][u][q] = lb[DB ? 1 : 0][u][q] = 0.0;
         fetch_meta(0);
-        fetch_multipliers(0, lb[0]);
-        if (DB) {
-            int pn = 0;
-            for (; pn + 1 < upto; pn += 2) {
-                panel_step(pn, upto, lb[0], lb[DB ? 1 : 0]);
-                panel_step(pn + 1, upto, lb[DB ? 1 : 0], lb[0]);
-            }
-            if (pn < upto) panel_step(pn, upto, lb[0], lb[DB ? 1 : 0]);
-        } else {
-            for (int pn = 0; pn < upto; ++pn) panel_step(pn, upto, lb[0], lb[0]);
-        }
+#pragma unroll
+        for (int u = 0; u < MT; ++u) fetch_tile(0, u, lb[u]);
+        for (int pn = 0; pn < upto; ++pn) panel_step(pn, upto);
     };
     if constexpr (FACTOR) {
         double *red_val = (double *)(tmeta + 2 * kMaxTouched + 4);  // [NW]
@@ -681,6 +711,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
         for (int q = 0; q < 4; ++q) blk[l15 * ld + pn * kNB + kq + 4 * q] = x[q];  // D[i = (lane >> 4) + 4 q][column lane & 15]
     }
     __syncthreads();
+#ifdef MPCX_RHS_STAMPS
+    __syncthreads();
+    if (bk == 0 && lane == 0) {
+        for (int k = 0; k < 4; ++k) p.X[(size_t)b * p.nr * p.nrhs + wv * 4 + k] = rs_sum[k];
+    }
+    return;
+#endif
     const double sign = p.negate ? -1.0 : 1.0;
     for (int e = tid; e < kNB * p.nr && !(MPCX_RHS_ABLATE & 16); e += THREADS) {
         const int c = e / p.nr, row = e - c * p.nr;
@@ -688,14 +725,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
     }
 }
 
-template <int THREADS, int MT, bool DB, bool FACTOR>
+template <int THREADS, int MT, bool FACTOR>
 int launch_apply(const RhsArgs &ra, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)lu_apply_kernel<THREADS, MT, DB, FACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)lu_apply_kernel<THREADS, MT, FACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     const long long grid = FACTOR ? ra.count : (ra.total + 7) / 8 * 8;
-    hipLaunchKernelGGL((lu_apply_kernel<THREADS, MT, DB, FACTOR>), dim3((unsigned)grid), dim3(THREADS), lds, s, ra);
+    hipLaunchKernelGGL((lu_apply_kernel<THREADS, MT, FACTOR>), dim3((unsigned)grid), dim3(THREADS), lds, s, ra);
     return 0;
 }
 
@@ -703,14 +740,13 @@ int launch_apply(const RhsArgs &ra, size_t lds, hipStream_t s) {
 template <bool FACTOR>
 int launch_apply_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
     const int npan = ra.nrp / kNB;
-    constexpr bool DB = true;
     if constexpr (!FACTOR) {  // (H of up to 256 rows is factored by lu_block_kernel)
-        if (npan <= 8) return launch_apply<256, 2, DB, FACTOR>(ra, lds, s);
-        if (npan <= 16) return launch_apply<256, 4, DB, FACTOR>(ra, lds, s);
+        if (npan <= 8) return launch_apply<256, 2, FACTOR>(ra, lds, s);
+        if (npan <= 16) return launch_apply<256, 4, FACTOR>(ra, lds, s);
     }
-    if (npan <= 32) return launch_apply<512, 4, DB, FACTOR>(ra, lds, s);
-    if (npan <= 56) return launch_apply<512, 7, DB, FACTOR>(ra, lds, s);
-    return launch_apply<512, 10, false, FACTOR>(ra, lds, s);
+    if (npan <= 32) return launch_apply<512, 4, FACTOR>(ra, lds, s);
+    if (npan <= 56) return launch_apply<512, 7, FACTOR>(ra, lds, s);
+    return launch_apply<512, 10, FACTOR>(ra, lds, s);
 }
 
 size_t rhs_lds_bytes(int nrp) {  // block, U12 / U11^-1, L11^-1, exchange lists, then the panel factorization's reduction slots and pivots
