@@ -60,6 +60,10 @@ struct LuArgs {
     long long count; // instances in this launch
     int nrp;
     double *meta;    // per instance and panel: L11^-1 and U11^-1 (256 doubles each), then tcount, trow[32], tsrc[32] as ints (kMetaDoubles in all)
+#ifdef MPCX_LU_STAMPS
+    double *dbg;     // diagnostic build: per instance the time spent loading panels, factoring them, sweeping the trailing columns
+    long long dbg_stride;
+#endif
 };
 constexpr int kMetaInts = 2 * kNB * kNB;                               // where the ints start, in doubles
 constexpr int kMetaDoubles = kMetaInts + (2 * kMaxTouched + 16) / 2;  // 512 + 40
@@ -309,6 +313,13 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
     double *A = p.ws + (size_t)blockIdx.x * nrp * nrp;
     double *mytile = tiles + wv * kNB * kNB;
 
+#ifdef MPCX_LU_STAMPS
+    long long bs_last = wall_clock64();
+    double bs_sum[3] = {0.0, 0.0, 0.0};
+#define BSTAMP(k) do { const long long now_ = wall_clock64(); bs_sum[k] += (double)(now_ - bs_last); bs_last = now_; } while (0)
+#else
+#define BSTAMP(k) do {} while (0)
+#endif
     for (int k0 = 0; k0 < nrp; k0 += kNB) {
         // 1. panel -> LDS (16 adjacent columns are one contiguous run of the workspace)
         {   // 16-byte pieces, eight loads in flight per thread (one memory latency per round, not one per element)
@@ -325,6 +336,7 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
             }
         }
         __syncthreads();
+        BSTAMP(0);
         // 2. factored in LDS; the panel goes back to the workspace (U11 is needed at the end) together with L11^-1,
         //    U11^-1 and the net effect of the 16 exchanges (which rows end up with whose old content)
         if (!factor_block<kThreads, kSmallRows / kThreads>(panel, nrp, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv,
@@ -337,6 +349,7 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
             if (tid == 0) p.failed[blockIdx.x] = 1;  // uniform over the workgroup
             return;
         }
+        BSTAMP(1);
         // 3. the columns to the right, one block of 16 per wavefront at a time
         const int ntouched = *tcount;
         d4 la;  // A operand of the triangular solve: (L11^-1)[lane & 15][(lane >> 4) + 4 kk]
@@ -383,8 +396,9 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
             for (int t = 0; t < nt; ++t) {
                 const int r0 = row0(t);
                 d4 acc = nxt;
-                if (t + 1 < nt) {
-                    const int r1 = row0(t + 1);
+                {   // (unconditional -- after the last tile the same tile again, unused: with a fixed number of loads and
+                    // stores per pass the wait for a tile is "all but the four stores issued since", not "everything")
+                    const int r1 = row0(t + 1 < nt ? t + 1 : t);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) nxt[q] = cbase[(size_t)(4 * q) * nrp + r1];
                 }
@@ -398,7 +412,12 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
             }
         }
         __syncthreads();  // the next panel's columns were written by other wavefronts of this workgroup
+        BSTAMP(2);
     }
+#ifdef MPCX_LU_STAMPS
+    if (tid == 0 && p.dbg)
+        for (int k = 0; k < 3; ++k) p.dbg[(size_t)blockIdx.x * p.dbg_stride + k] = bs_sum[k];
+#endif
 }
 
 // ---- right-hand sides: one workgroup per instance and block of 16 columns, the block resident in LDS ----
@@ -448,6 +467,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
     double *u12s = blk + (size_t)kNB * ld;  // [16][16]: u12s[row * 16 + col]
     double *linv = u12s + kNB * kNB;        // [16][16]
     int *tmeta = (int *)(linv + kNB * kNB); // tcount, trow[32], tsrc[32]
+#ifdef MPCX_RHS_STAMPS
+    const long long rs_t0 = wall_clock64();
+    long long rs_t1 = 0, rs_t2 = 0;
+#endif
     const bool bad = !FACTOR && p.failed[li] != 0;
     if (!FACTOR && p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
     const long long ER = (long long)p.nr * p.nrhs;
@@ -469,10 +492,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
     // tile, or the panel's own tile, reads the last tile / itself and the value is dropped): with a fixed number of loads
     // per step the compiler can wait for "all but the loads issued since" when a multiplier is first used; behind a
     // condition it cannot, and waits for every outstanding load.
-    auto fetch_tile = [&](int pn, int u, double(&dst)[4]) __attribute__((always_inline)) {
+    auto fetch_one = [&](int pn, int u, int q) __attribute__((always_inline)) {
         const int t0 = wvs + NW * u, t = t0 < npan ? t0 : npan - 1;
+        return A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
+    };
+    auto fetch_tile = [&](int pn, int u, double(&dst)[4]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
+        for (int q = 0; q < 4; ++q) dst[q] = fetch_one(pn, u, q);
     };
     // A panel's description is fetched one panel ahead: L11^-1 one entry per thread (it reaches the first wavefront
     // through LDS), and in the first wavefront the rows the 16 pivot rows come from, in the layout its
@@ -515,6 +541,40 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
         }
         const double *qw = q_lds ? u12s : p.Q;
         const int cc = c0 + l15, g = cc / r, a2 = cc - g * r, joff = lo - g * r;  // A operand: column lane & 15
+        if (ns <= 6) {
+            // (the usual case: the 16 columns touch at most 24 rows of Gamma)  Four tiles of a wavefront at a time, every
+            // load of the four issued before the first product: one memory latency per four tiles.
+            constexpr int TB = 4, NS = 6;
+            double qa[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int jj = 4 * u + kq, ja = jj + joff;
+                qa[u] = (cc < p.nrhs && jj < w && ja >= 0 && ja < r) ? qw[a2 * r + ja] : 0.0;
+            }
+            for (int tb0 = wv; tb0 < npan; tb0 += NW * TB) {
+                double gb[TB][NS];
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    const int t = tb0 + i * NW, k = t * kNB + l15;  // B operand: unknown lane & 15
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) {
+                        const int jj = 4 * u + kq;
+                        gb[i][u] = (t < npan && k < p.nr && jj < w) ? p.R[elem_index(b, (long long)k * p.nrhs + lo + jj, ER, p.W)] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    const int t = tb0 + i * NW;
+                    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[u], gb[i][u], acc, 0, 0, 0);  // (zeros past w)
+                    if (t < npan) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) blk[(kq + 4 * q) * ld + t * kNB + l15] = acc[q];
+                    }
+                }
+            }
+        } else {
         constexpr int SC = 12;  // steps of four rows of Gamma in flight per tile
         for (int t = wv; t < npan; t += NW) {
             const int k = t * kNB + l15;  // B operand: unknown lane & 15
@@ -533,6 +593,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) blk[(kq + 4 * q) * ld + t * kNB + l15] = acc[q];
+        }
         }
         __syncthreads();  // the weight block leaves the U12 buffer
     }
@@ -685,44 +746,55 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
         }
         return;
     }
+#ifdef MPCX_RHS_STAMPS
+    rs_t1 = wall_clock64();
+#endif
     apply_panels(npan);
-    double un[4];  // this wavefront's next U11^-1 operand for the last step
-    auto fetch_uinv = [&](int pn) {
+#ifdef MPCX_RHS_STAMPS
+    rs_t2 = wall_clock64();
+#endif
+    // x_p = U11_p^-1 y_p per panel, in place: one 16x16x16 product per panel, panels dealt to the wavefronts.  Every
+    // inverse of the wavefront's panels is requested before the first product (the multipliers' registers are free now).
+    double un[MT][4];
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+        const int pn0 = wvs + NW * u, pn = pn0 < npan ? pn0 : npan - 1;
         const double *ui = meta + (size_t)pn * kMetaDoubles + kNB * kNB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) un[q] = ui[l15 * kNB + kq + 4 * q];
-    };
-    if (wv < npan) fetch_uinv(wv);
+        for (int q = 0; q < 4; ++q) un[u][q] = ui[l15 * kNB + kq + 4 * q];  // A operand: U11^-1[i = lane & 15][k]
+    }
     __syncthreads();
-    // x_p = U11_p^-1 y_p per panel, in place: one 16x16x16 product per panel, panels dealt to the wavefronts (each
-    // further inverse is fetched while its predecessor is applied)
-    for (int pn = wv; pn < npan && !(MPCX_RHS_ABLATE & 8); pn += NW) {
-        double ua[4], yb[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ua[q] = un[q];                                   // A operand: U11^-1[i = lane & 15][k]
-            yb[q] = blk[l15 * ld + pn * kNB + kq + 4 * q];   // B operand: y[k][column lane & 15]
+    for (int u = 0; u < MT; ++u) {
+        const int pn = wvs + NW * u;
+        if (pn < npan && !(MPCX_RHS_ABLATE & 8)) {
+            double yb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) yb[q] = blk[l15 * ld + pn * kNB + kq + 4 * q];  // B operand: y[k][column lane & 15]
+            d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(un[u][q], yb[q], x, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) blk[l15 * ld + pn * kNB + kq + 4 * q] = x[q];  // D[i = (lane >> 4) + 4 q][column lane & 15]
         }
-        if (pn + NW < npan) fetch_uinv(pn + NW);
-        d4 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[q], yb[q], x, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) blk[l15 * ld + pn * kNB + kq + 4 * q] = x[q];  // D[i = (lane >> 4) + 4 q][column lane & 15]
     }
     __syncthreads();
-#ifdef MPCX_RHS_STAMPS
-    __syncthreads();
-    if (bk == 0 && lane == 0) {
-        for (int k = 0; k < 4; ++k) p.X[(size_t)b * p.nr * p.nrhs + wv * 4 + k] = rs_sum[k];
-    }
-    return;
-#endif
     const double sign = p.negate ? -1.0 : 1.0;
     for (int e = tid; e < kNB * p.nr && !(MPCX_RHS_ABLATE & 16); e += THREADS) {
         const int c = e / p.nr, row = e - c * p.nr;
         if (c0 + c < p.nrhs) p.X[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] = sign * blk[(size_t)c * ld + row];
     }
+#ifdef MPCX_RHS_STAMPS
+    __syncthreads();  // (orders this workgroup's result stores before the stamps that overwrite some of them)
+    if (bk == 1 && lane == 0) {  // block 1: a block in the middle of the launch's work, written last of its instance's first columns
+        double *o = p.X + (size_t)b * p.nr * p.nrhs + wv * 8;
+        for (int k = 0; k < 4; ++k) o[k] = rs_sum[k];
+        const long long t3 = wall_clock64();
+        o[4] = (double)(rs_t1 - rs_t0);
+        o[5] = (double)(rs_t2 - rs_t1);
+        o[6] = (double)(t3 - rs_t2);
+    }
+#endif
 }
 
 template <int THREADS, int MT, bool FACTOR>
@@ -800,6 +872,10 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         else
             hipLaunchKernelGGL(lu_pack_kernel, dim3((unsigned)pblocks), dim3(256), 0, s, pa);
         LuArgs la{ws, failed, count, nrp, meta};
+#ifdef MPCX_LU_STAMPS
+        la.dbg = X + (size_t)first * nr * nrhs;
+        la.dbg_stride = (long long)nr * nrhs;
+#endif
         RhsArgs ra{ws, failed, meta, R, Q, X, info, first, count, W, 0, nr, nrhs, r, nrp, negate, rhs_ld(nrp)};
         if (left_looking(nrp)) {
             const int rc = launch_apply_any<true>(ra, rhs_bytes, s);
@@ -811,7 +887,7 @@ int launch_solve_large(const double *H, const double *R, const double *Q, int r,
         if (per_xcd * 8 > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
         ra.total = total;
 #ifdef MPCX_LU_STAMPS
-        if (left_looking(nrp)) continue;  // diagnostic build: the factorisation's time stamps stay in X
+        continue;  // diagnostic build: the factorisation's time stamps stay in X
 #endif
         if (total > 0) {
             const int rc = launch_apply_any<false>(ra, rhs_bytes, s);

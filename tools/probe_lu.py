@@ -22,6 +22,11 @@ for _ in range(2):
     ctx.qp_gain_dev(dims, H.data_ptr(), Gam.data_ptr(), bufs["Q"].data_ptr(), gain.data_ptr(), info.data_ptr(), 0)
 torch.cuda.synchronize()
 npan = (VM + 15) // 16
+if npan * 16 <= 256:  # right-looking kernel: three sums per instance
+    st = gain.cpu().numpy().reshape(count, VM * FR)[:, :3] / 100.0
+    print("per instance (us): panel loads %.1f  panel factorisations %.1f  trailing sweeps %.1f  total %.1f; per panel %.2f / %.2f / %.2f" %
+          (*st.mean(axis=0), st.sum(axis=1).mean(), *(st.mean(axis=0) / npan)))
+    sys.exit(0)
 st = gain.cpu().numpy().reshape(count, VM * FR)[:, : 4 * npan].reshape(count, npan, 4) / 100.0  # us
 load, apply_, fact = st[:, :, 1] - st[:, :, 0], st[:, :, 2] - st[:, :, 1], st[:, :, 3] - st[:, :, 2]
 print("per instance: load %.0f us, apply %.0f us, factor+store %.0f us, total %.0f us" %

@@ -25,7 +25,9 @@ for _ in range(2):
 torch.cuda.synchronize()
 npan = (VM + 15) // 16
 nw = 8 if npan > 16 else 4
-st = gain.cpu().numpy().reshape(count, VM * FR)[:, : 4 * nw].reshape(count, nw, 4).mean(axis=0) / 100.0 / npan  # us per panel step
+raw = gain.cpu().numpy().reshape(count, VM * FR)[:, : 8 * nw].reshape(count, nw, 8).mean(axis=0) / 100.0  # us
+st = raw[:, :4] / npan  # per panel step
 names = ["wait at barrier 1", "section + requests", "wait at barrier 2", "tile updates"]
 for w in range(nw):
     print(f"wavefront {w}: " + "  ".join(f"{nm} {x:5.2f}" for nm, x in zip(names, st[w])) + f"   step {st[w].sum():5.2f} us")
+print("whole block (wavefront 0): forming the block %.1f us, %d panel steps %.1f us, U11 step and result %.1f us" % (raw[0, 4], npan, raw[0, 5], raw[0, 6]))
