@@ -549,6 +549,260 @@ __global__ __launch_bounds__(kGroupThreads, NP >= 8 ? 2 : 3) void closed_loop_ro
 #undef IN
 }
 
+// The loop with the window products taken out of it.  u_t = K (w_t - Phi x_t) with w_t the reference window of step t is
+// computed as u_t = K w_t - (K Phi) x_t: the m x n matrix K Phi is formed once per instance, and the products
+// v_t = K w_t do not depend on the state, so all T of them are formed in parallel ahead of the serial recursion -- one
+// lane per step, K shared through LDS -- instead of f r multiply-adds and a workgroup reduction inside every step.
+// What stays serial is u_t = v_t - (K Phi) x_t (m x n), y_t = C x_t and x_{t+1} = A x_t + B u_t, run by one wavefront with
+// the state broadcast lane to lane (no LDS, no barrier in the recursion).  Same trajectory as compute_control_input
+// followed by propagate_dynamics (controller.rs:119-132, 101-115) up to the rounding of the regrouped product (the
+// bound is that of K s itself: |K| |w| eps); A x + B u and C x keep the reference's order.
+// Steps go in chunks of 64: reference columns -> LDS (transposed: a lane walks its window with unit stride), the four
+// wavefronts each take a quarter of the window rows for all 64 steps, their partial sums are added, one wavefront runs
+// the 64 steps into an LDS staging area, all flush it.  m <= 4, n <= 12, r <= 16.
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kAffChunk = 64;
+template <int NP>
+__global__ __launch_bounds__(kGroupThreads, 3) void closed_loop_affine_kernel(LoopArgs p) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long b = blockIdx.x;
+    const int n = p.n, m = p.m, r = p.r, F = p.f, FR = F * r, VM = p.v * m;
+    const long long W = p.W, tile = b / W, li = b - tile * W, T = p.T;
+    const long long L = T + F, ER = (long long)r * L;
+    constexpr int TC = kAffChunk;
+    const int RL = TC + F - 1, ops = n + m + r;  // reference columns a chunk touches; doubles a step leaves behind
+    // The window of step tl is the run of F columns from column tl on: with the columns stored one after the other, row
+    // c' of every window is at a fixed distance from the window's start and the products are one flat loop.  A column takes
+    // rp = r | 1 doubles (an odd stride keeps the lanes, one per step, on distinct LDS banks); the pad entry of a column
+    // is zero in the reference and in K.
+    const int rp = r | 1, FP = F * rp;
+#define IN(ptr, E, e) ((ptr)[tile * (long long)(E) * W + (long long)(e) * W + li])
+    double *sA = lds, *sB = sA + n * n, *sC = sB + n * m, *sKP = sC + r * n;  // sKP[k * NP + j] = (K Phi)[k][j]
+    double *sK = sKP + 4 * NP;                                                // sK[(i rp + a) * 4 + k] = K[k][i r + a] (zero for k >= m, a = r)
+    double *sRef = sK + (size_t)FP * 4;                                       // sRef[(tau - t0) * rp + a]
+    double *sV = sRef + (size_t)rp * RL;                                      // sV[tl * 4 + k]
+    double *sOut = sV + TC * 4;                                               // [tl][x_{t+1} (n) | u_t (m) | y_t (r)]; also the partial sums
+    double *sPart = sOut;                                                     // sPart[(w * TC + tl) * 4 + k], and K Phi's partial sums
+    for (int e = tid; e < n * n; e += kGroupThreads) sA[e] = IN(p.A, n * n, e);
+    for (int e = tid; e < n * m; e += kGroupThreads) sB[e] = IN(p.B, n * m, e);
+    for (int e = tid; e < r * n; e += kGroupThreads) sC[e] = IN(p.C, r * n, e);
+    for (int e = tid; e < FP * 4; e += kGroupThreads) {
+        const int cp = e >> 2, k = e & 3, i = cp / rp, a = cp - i * rp;
+        sK[e] = (k < m && a < r) ? IN(p.gain, (long long)VM * FR, (long long)(i * r + a) * VM + k) : 0.0;
+    }
+    if (rp > r)
+        for (int e = tid; e < RL; e += kGroupThreads) sRef[e * rp + r] = 0.0;  // the pad entries
+    const long long EX = (long long)n * (T + 1), EY = (long long)r * T, EU = (long long)m * T;
+    // the reference columns of a chunk, requested a chunk ahead (element e of the chunk: column t0 + e / r, row e % r)
+    constexpr int kPre = 6;  // registers per thread; chunks with more columns load the rest in place
+    const int nref = r * RL;
+    double pre[kPre];
+    auto request_ref = [&](long long t0) {
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const int e = tid + q * kGroupThreads;
+            long long tau = t0 + e / r;
+            if (e >= nref || tau >= L) tau = L - 1;  // (a valid address, unused)
+            const long long idx = tau * r + e % r;
+            pre[q] = p.ref_shared ? p.ref[idx] : IN(p.ref, ER, idx);
+        }
+    };
+    request_ref(0);
+    __syncthreads();
+    // Diagnostic build (-DMPCX_LOOP_STAMPS, tools/probe_loop.py): thread 0 adds up the time of each phase and leaves the sums
+    // at the start of its instance's X.
+#ifdef MPCX_LOOP_STAMPS
+    long long ls_last = wall_clock64();
+    double ls_sum[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#define LSTAMP(k) do { const long long now_ = wall_clock64(); ls_sum[k] += (double)(now_ - ls_last); ls_last = now_; } while (0)
+#else
+#define LSTAMP(k) do {} while (0)
+#endif
+    // ---- K Phi: a wavefront takes NP / 4 columns of Phi, lanes along the window rows (Phi read once, coalesced) ----
+    {
+        constexpr int NPW = NP / 4;
+        double acc[4][NPW];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int jj = 0; jj < NPW; ++jj) acc[k][jj] = 0.0;
+        for (int c = lane; c < FR; c += kWave) {
+            double ph[NPW], kv[4];
+#pragma unroll
+            for (int jj = 0; jj < NPW; ++jj) {
+                const int j = wv * NPW + jj;
+                ph[jj] = j < n ? IN(p.Phi, (long long)FR * n, (long long)j * FR + c) : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) kv[k] = k < m ? IN(p.gain, (long long)VM * FR, (long long)c * VM + k) : 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int jj = 0; jj < NPW; ++jj) acc[k][jj] += kv[k] * ph[jj];
+        }
+        // rows of 16 lanes by lane-to-lane moves, the wavefront's four row sums through LDS
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int jj = 0; jj < NPW; ++jj) {
+                double v = acc[k][jj];
+                v += dpp_f64<0xB1>(v);
+                v += dpp_f64<0x4E>(v);
+                v += dpp_f64<0x124>(v);
+                v += dpp_f64<0x128>(v);
+                if ((lane & 15) == 0) sPart[(lane >> 4) * 4 * NP + k * NP + wv * NPW + jj] = v;
+            }
+        __syncthreads();
+        if (tid < 4 * NP) sKP[tid] = (sPart[tid] + sPart[4 * NP + tid]) + (sPart[8 * NP + tid] + sPart[12 * NP + tid]);
+        __syncthreads();
+    }
+    LSTAMP(0);
+    // ---- the serial wavefront: lane l holds x_l (and, inside a chunk, row l of A, B, C and of K Phi) ----
+    // Which wavefront runs the recursion differs from workgroup to workgroup (a hash of the workgroup's index): the
+    // workgroups that share a CU would otherwise all run it on the same SIMD, one behind the other.
+    const int sw = (int)((blockIdx.x * 2654435761u) >> 30);
+    double xj = 0.0;
+    if (wv == sw && lane < n) {
+        xj = IN(p.x0, n, lane);
+        if (p.X) IN(p.X, EX, lane) = xj;
+    }
+    for (long long t0 = 0; t0 < T; t0 += TC) {
+        const int steps = (int)((T - t0 < TC) ? T - t0 : TC);
+        // reference columns t0 .. t0 + steps + F - 2, transposed
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const int e = tid + q * kGroupThreads;
+            if (e < nref) sRef[(e / r) * rp + e % r] = pre[q];
+        }
+        for (int e = tid + kPre * kGroupThreads; e < nref; e += kGroupThreads) {
+            long long tau = t0 + e / r;
+            if (tau >= L) tau = L - 1;
+            const long long idx = tau * r + e % r;
+            sRef[(e / r) * rp + e % r] = p.ref_shared ? p.ref[idx] : IN(p.ref, ER, idx);
+        }
+        __syncthreads();
+        LSTAMP(1);
+        // v_t = K w_t: lane tl is step t0 + tl, this wavefront's quarter of the (padded) window rows
+        {
+            const int c0 = (FP * wv) / kGroupWaves, c1 = (FP * (wv + 1)) / kGroupWaves;
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
+            const double *rl = sRef + lane * rp;
+            constexpr int UN = 8;  // rows per pass: every LDS read of the pass is issued before its multiply-adds
+            int c = c0;
+            for (; c + UN <= c1; c += UN) {
+                double w[UN], kv[UN][4];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    w[u] = rl[c + u];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) kv[u][k] = sK[(c + u) * 4 + k];
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += kv[u][k] * w[u];
+            }
+            for (; c < c1; ++c) {
+                const double w = rl[c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += sK[c * 4 + k] * w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sPart[(wv * TC + lane) * 4 + k] = v[k];
+        }
+        __syncthreads();
+        LSTAMP(2);
+        {
+            double v = 0.0;  // thread (tl, k)
+#pragma unroll
+            for (int w = 0; w < kGroupWaves; ++w) v += sPart[w * TC * 4 + tid];
+            sV[tid] = v;
+        }
+        __syncthreads();
+        if (t0 + TC < T) request_ref(t0 + TC);  // (ahead of this chunk's stores)
+        LSTAMP(3);
+        if (wv == sw) {
+            // Lanes 0..15 hold the rows of A (and of B), lanes 16..31 the rows of C, lanes 32..35 the rows of K Phi: a step
+            // is one dot product of length n per lane, all three families side by side.  x_j lives in lane j.
+            const int grp = lane >> 4, l15 = lane & 15;
+            double row[NP], rowB[4];  // (read here, chunk by chunk: not live across the window products)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                double v = 0.0;
+                if (j < n) {
+                    if (grp == 0 && l15 < n) v = sA[j * n + l15];
+                    else if (grp == 1 && l15 < r) v = sC[j * r + l15];
+                    else if (grp == 2 && l15 < 4) v = sKP[l15 * NP + j];
+                }
+                row[j] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rowB[k] = (lane < n && k < m) ? sB[k * n + lane] : 0.0;
+            const int vk = (grp == 2 && l15 < 4) ? l15 : 0;
+            // where this lane's result of a step goes ([x_{t+1} | u_t | y_t] of the step; idle lanes share a spare slot)
+            const int slot = lane < n ? lane : (grp == 1 && l15 < r) ? n + m + l15 : (grp == 2 && l15 < m) ? n + l15 : -1;
+            double vn = sV[vk];  // v of the first step, lanes 32 + k
+            for (int q = 0; q < steps; ++q) {
+                const double vt = vn;
+                vn = sV[((q + 1 < steps) ? q + 1 : q) * 4 + vk];
+                double xs[NP];  // the state, every entry in scalar registers before the first product
+#pragma unroll
+                for (int j = 0; j < NP; ++j) xs[j] = lane_bcast(xj, j);
+                double dot = 0.0;  // lanes < 16: (A x)_l; 16..31: y_l = (C x)_l; 32..35: ((K Phi) x)_k
+#pragma unroll
+                for (int j = 0; j < NP; ++j) dot += row[j] * xs[j];
+                const double uk = vt - dot;  // lanes 32 + k: the move
+                double us[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) us[k] = lane_bcast(uk, 32 + k);
+                double bu = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bu += rowB[k] * us[k];
+                const double xnew = dot + bu;
+                if (lane < n) xj = xnew;
+                const double res = grp == 0 ? xnew : grp == 1 ? dot : uk;
+                sOut[slot >= 0 ? q * ops + slot : TC * ops] = res;
+            }
+        }
+        __syncthreads();
+        LSTAMP(4);
+        // flush the chunk: X columns t0+1 .. t0+steps are contiguous per instance, likewise U and Y
+        if (p.X)
+            for (int e = tid; e < steps * n; e += kGroupThreads) IN(p.X, EX, (t0 + 1) * n + e) = sOut[(e / n) * ops + (e % n)];
+        if (p.U)
+            for (int e = tid; e < steps * m; e += kGroupThreads) IN(p.U, EU, t0 * m + e) = sOut[(e / m) * ops + n + (e % m)];
+        if (p.Y)
+            for (int e = tid; e < steps * r; e += kGroupThreads) IN(p.Y, EY, t0 * r + e) = sOut[(e / r) * ops + n + m + (e % r)];
+        __syncthreads();
+        LSTAMP(5);
+    }
+#ifdef MPCX_LOOP_STAMPS
+    if (tid == 0 && p.X)
+        for (int k = 0; k < 6; ++k) IN(p.X, EX, k) = ls_sum[k];
+#endif
+#undef IN
+}
+
+size_t affine_lds_bytes(const LoopArgs &a, int np) {
+    const size_t out = (size_t)kAffChunk * (a.n + a.m + a.r) + 1, part = (size_t)kGroupWaves * kAffChunk * 4, kp = (size_t)4 * 4 * np;
+    size_t stage = out > part ? out : part;
+    if (kp > stage) stage = kp;
+    const size_t rp = (size_t)(a.r | 1);
+    size_t d = (size_t)a.n * a.n + (size_t)a.n * a.m + (size_t)a.r * a.n + 4 * np + (size_t)a.f * rp * 4 +
+               rp * (kAffChunk + a.f - 1) + kAffChunk * 4 + stage;
+    return d * sizeof(double);
+}
+template <int NP>
+int launch_affine(const LoopArgs &a, hipStream_t s) {
+    const size_t lds_bytes = affine_lds_bytes(a, NP);
+    hipLaunchKernelGGL((closed_loop_affine_kernel<NP>), dim3((unsigned)a.batch), dim3(kGroupThreads), lds_bytes, s, a);
+    return (int)hipGetLastError();
+}
+
 size_t rows_lds_bytes(const LoopArgs &a) {
     size_t d = (size_t)a.n * a.n + (size_t)a.n * a.m + (size_t)a.r * a.n + 2 * a.n + 2 * kGroupWaves * 4 +
                (size_t)kChunk * (a.n + a.m + a.r) + (size_t)(a.f + kChunk) * a.r;
@@ -591,6 +845,14 @@ int launch_closed_loop_lane(const LoopArgs &a, hipStream_t s) {
 int launch_closed_loop_group(const LoopArgs &a, hipStream_t s) {
     if (a.n > kWave || a.m > kWave || a.r > kWave) return MPCX_ERR_UNSUPPORTED;
     if (a.batch > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    // few inputs, a state of at most 16 entries: the window products leave the loop
+#ifndef MPCX_NO_AFFINE
+    if (a.m <= 4 && a.n <= 12 && a.r <= 16 && affine_lds_bytes(a, 12) <= 64 * 1024) {
+        if (a.n <= 4) return launch_affine<4>(a, s);
+        if (a.n <= 8) return launch_affine<8>(a, s);
+        return launch_affine<12>(a, s);
+    }
+#endif
     // few inputs and a window of at most 768 rows: Phi and the gain rows live in registers
     if (a.m <= 4 && a.n <= 16 && (long long)a.f * a.r <= 3 * kGroupThreads && rows_lds_bytes(a) <= 64 * 1024) {
         if (a.n <= 4) return launch_rows_np<4>(a, s);
