@@ -258,6 +258,9 @@ int mpcx_plants_f64_dev(mpcx_ctx *ctx, int kind, int64_t batch, int64_t interlea
  * Outputs (any may be NULL): X n x (T+1) with X[:,0] = x0; U m x T; Y r x T.  The reference's `outputs` matrix
  * (main.rs:40-41, :63) is [C x0, Y[:,0], Y[:,1], ...].  The reference handles m = r = 1 only; larger m, r follow the
  * same formulas with the window stacked as ref[a, t+i] at row i r + a.
+ * Instance-major batches of plants with m <= 4, n <= 12, r <= 16 evaluate u_t as K ref_window - (K Phi) x_t (K the first
+ * m gain rows; the products with the reference windows are formed ahead of the serial steps): the same trajectories up
+ * to the rounding of the regrouped product, which the tests hold to 1e-10 (relative, Frobenius) of the reference's order.
  */
 int mpcx_closed_loop_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, const double *B, const double *C,
                          const double *x0, const double *Phi, const double *gain, const double *ref, double *X, double *U,

@@ -12,6 +12,8 @@
 //   closed_loop_lane   tiny plants: one lane per instance; A, B, C, x in registers; Phi and the first gain rows in a
 //                      per-lane LDS column (no barriers: a lane only ever touches its own column).
 //   closed_loop_group  any n, m, r <= 64: one workgroup of four wavefronts per instance, everything in LDS.
+//   closed_loop_affine instance-major batches with m <= 4, n <= 12, r <= 16: the window products leave the recursion
+//                      (u_t = K w_t - (K Phi) x_t), see the kernel.
 // Loads and stores of a wave retire through one in-order counter, so a load issued after a store cannot be consumed
 // before that store has reached memory.  Both kernels therefore fetch the per-instance reference a chunk of kChunk
 // steps ahead: the wait for a chunk's loads only covers stores that are a whole chunk old.  A reference shared by the
