@@ -27,7 +27,7 @@ CASES = {
     "gain_two_mass": ("gain:two_mass:1048576:20:20", r"solve_rows_kernel"),
     "gain_rows_two_mass": ("gain_rows:two_mass:1048576:20:20", r"solve_rows_kernel|rows_lane_kernel|unit_columns_kernel"),
     "loop_two_mass": ("loop:two_mass:1048576:20:20", r"closed_loop_lane_kernel"),
-    "loop_quadrotor": ("loop:quadrotor:16384:50:50", r"closed_loop_rows_kernel|closed_loop_group_kernel"),
+    "loop_quadrotor": ("loop:quadrotor:16384:50:50", r"closed_loop_affine_kernel|closed_loop_rows_kernel|closed_loop_group_kernel"),
     "gain_quadrotor": ("gain:quadrotor:16384:50:50", r"lu_\w+"),
     "gain_rows_quadrotor": ("gain_rows:quadrotor:16384:50:50", r"lu_\w+|rows_wg_kernel|unit_columns_kernel"),
     "gain_long": ("gain:long:1024:400:400", r"lu_\w+"),
