@@ -119,8 +119,16 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
 #ifdef MPCX_LU_STAMPS
                                           , double *dbg
 #define FSTAMP(k) do { if (threadIdx.x == 0 && dbg) dbg[k] = (double)wall_clock64(); } while (0)
+#ifdef MPCX_LU_STAMPS2  // the inside of column 8 instead of the column times: slots 1..6
+#undef FSTAMP
+#define FSTAMP(k) do {} while (0)
+#define CSTAMP(jc_, k) do { if ((jc_) == 8 && threadIdx.x == 0 && dbg) dbg[1 + (k)] = (double)wall_clock64(); } while (0)
+#endif
 #else
 #define FSTAMP(k) do {} while (0)
+#endif
+#ifndef CSTAMP
+#define CSTAMP(jc_, k) do {} while (0)
 #endif
                                           ) {
     constexpr int NW = THREADS / 64;
@@ -158,20 +166,53 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
                 if (x > best || (x == best && pos[u] < bi)) { best = x; bi = pos[u]; }
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best, off);
-            const int oi = __shfl_xor(bi, off);
+        CSTAMP(jc, 0);
+        // The wavefront's candidate: rows of 16 lanes by lane-to-lane moves (the rule "larger value, then smaller
+        // position" is idempotent, so rotations serve as well as exchanges), the four row results through scalar
+        // registers.  (Six rounds of cross-lane shuffles took 0.65 us of a column's 2.2.)
+        auto take = [&](double ob, int oi) {
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        };
+        take(dpp_f64<0xB1>(best), __builtin_amdgcn_mov_dpp(bi, 0xB1, 0xf, 0xf, false));    // lane ^ 1
+        take(dpp_f64<0x4E>(best), __builtin_amdgcn_mov_dpp(bi, 0x4E, 0xf, 0xf, false));    // lane ^ 2
+        take(dpp_f64<0x124>(best), __builtin_amdgcn_mov_dpp(bi, 0x124, 0xf, 0xf, false));  // rotate by 4 within the row
+        take(dpp_f64<0x128>(best), __builtin_amdgcn_mov_dpp(bi, 0x128, 0xf, 0xf, false));  // rotate by 8
+        {
+            double rb[4];
+            int ri[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rb[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 16 * q),
+                                         __builtin_amdgcn_readlane(__double2loint(best), 16 * q));
+                ri[q] = __builtin_amdgcn_readlane(bi, 16 * q);
+            }
+            best = rb[0];
+            bi = ri[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) take(rb[q], ri[q]);
         }
+        CSTAMP(jc, 1);
         if (lane == 0) { red_val[wv] = best; red_idx[wv] = bi; }
         __syncthreads();
-        best = red_val[0];
-        bi = red_idx[0];
+        CSTAMP(jc, 2);
+        {   // every wavefront's candidate read before the first comparison, compared as a tree
+            double cb[NW];
+            int ci[NW];
 #pragma unroll
-        for (int w2 = 1; w2 < NW; ++w2) {
-            const double ob = red_val[w2];
-            const int oi = red_idx[w2];
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            for (int w2 = 0; w2 < NW; ++w2) {
+                cb[w2] = red_val[w2];
+                ci[w2] = red_idx[w2];
+            }
+#pragma unroll
+            for (int span = 1; span < NW; span *= 2)
+#pragma unroll
+                for (int w2 = 0; w2 + span < NW; w2 += 2 * span)
+                    if (cb[w2 + span] > cb[w2] || (cb[w2 + span] == cb[w2] && ci[w2 + span] < ci[w2])) {
+                        cb[w2] = cb[w2 + span];
+                        ci[w2] = ci[w2 + span];
+                    }
+            best = cb[0];
+            bi = ci[0];
         }
         if (!(best > 0.0) || !isfinite(best)) { failed = true; return; }
         if (tid == 0) ipiv[jc] = bi;
@@ -185,7 +226,9 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
                 pos[u] = bi;
             }
         }
+        CSTAMP(jc, 3);
         __syncthreads();
+        CSTAMP(jc, 4);
         double pv[kNB];
 #pragma unroll
         for (int c = jc; c < kNB; ++c) pv[c] = pbuf[c];
@@ -198,6 +241,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
 #pragma unroll
             for (int c = jc + 1; c < kNB; ++c) a[u][c] -= l * pv[c];
         }
+        CSTAMP(jc, 5);
         FSTAMP(1 + jc);
     });
     if (failed) return false;
