@@ -171,6 +171,13 @@ int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, 
  * inverses, evaluated with multiply and add kept separate, failing exactly where try_inverse returns None, on
  * `determinant == 0.0`; the one deviation is that a non-finite determinant is flagged as well.  Above 4 unknowns:
  * Gaussian elimination with partial pivoting per instance, as nalgebra's LU; an exactly zero or non-finite pivot fails.
+ * Up to 64 unknowns (with right-hand sides that fit 64 KB of LDS beside the matrix: every solve, first-move rows and
+ * discretisation of that size, gains of up to about 60 outputs x horizon) the elimination goes column by column like the
+ * reference's, so a matrix that is singular only
+ * through exact cancellation (two equal rows, say) meets its exactly zero pivot here as it does there.  Larger systems
+ * are eliminated in panels of 16 columns on the matrix cores with the same pivoting rule: zero rows or columns and
+ * non-finite entries are flagged at every size, but a cancellation that relies on two rows seeing identical rounding
+ * may leave a tiny non-zero pivot instead (info 0, a meaningless finite result, as for any numerically singular H).
  * Results agree with the reference's to the 1e-10 bar scaled by the condition number.
  *   mpcx_qp_solve:  u_seq (v m per instance) = -H^-1 fvec: the optimal input sequence; its first m entries are the
  *                   move the reference applies (controller.rs:130-134 with gain s = -H^-1 fvec).
@@ -179,10 +186,11 @@ int mpcx_rollout_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const double *A, 
  * `info` (int32 per instance, plain array of `batch` entries, may be NULL) is 0 on success and 1 where the reference
  * returns Err("Matrix inversion failed") (controller.rs:93-95): an exactly zero or non-finite pivot; the outputs of
  * such an instance are NaN.  The call itself still returns MPCX_OK.  H, fvec, Gamma, u_seq, gain use dims->interleave.
- * Limits: v m <= 1232 unknowns (a block of 16 columns of all rows has to fit the 160 KB of LDS); systems that do not
- * fit LDS whole go through a device workspace the context owns ((v m)^2 doubles per instance in flight; it grows on
- * demand, see mpcx_reserve); there the r x r weight block of mpcx_qp_gain is limited to r <= 64.  Beyond these:
- * MPCX_ERR_UNSUPPORTED.
+ * Limits: v m <= 1232 unknowns (a block of 16 columns of all rows has to fit the 160 KB of LDS); systems beyond 64
+ * unknowns (or with more right-hand sides than a wavefront's LDS share holds beside them) go through a device workspace
+ * the context owns ((v m)^2 doubles per instance in flight; it grows on demand, see mpcx_reserve); there the r x r weight
+ * block of mpcx_qp_gain is served up to r = 64 on the matrix cores (wider blocks, for up to about 140 unknowns, by a plain
+ * and much slower kernel).  Beyond these: MPCX_ERR_UNSUPPORTED.
  */
 int mpcx_qp_solve_f64(mpcx_ctx *ctx, const mpcx_dims *dims, const double *H, const double *fvec, double *u_seq,
                       int32_t *info);
@@ -227,7 +235,8 @@ int mpcx_c2d_backward_euler_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const 
  * library runs on, held until the process ends), whose address on the context's device mpcx_create resolves.
  * Limits, reported as MPCX_ERR_UNSUPPORTED with a message: mpcx_array_elems(batch, interleave, n n) must not exceed
  * MPCX_C2D_NOALLOC_MAX_DOUBLES (plants the one-lane kernels take -- n <= 6 with m <= 2 -- need no scratch and have no
- * such limit), and n must be small enough for the on-chip solver (n <= 100).  All calls on one GPU share that GPU's
+ * such limit), and n must be small enough for a solver that needs no workspace (n <= 100; from n = 64 on that is a plain
+ * LDS kernel, several times slower than the workspace-backed solver of the _dev call).  All calls on one GPU share that GPU's
  * array: two such calls that overlap in time on one device (different streams or contexts) race.
  */
 #define MPCX_C2D_NOALLOC_MAX_DOUBLES ((int64_t)1 << 21)

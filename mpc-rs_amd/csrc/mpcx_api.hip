@@ -800,7 +800,7 @@ int mpcx_c2d_backward_euler_f64_noalloc_dev(mpcx_ctx *ctx, const mpcx_dims *d, c
     hipStream_t s = (hipStream_t)stream;
     rc = launch_c2d_lane(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, s);  // tiny plants: registers only, no scratch
     if (rc == MPCX_ERR_UNSUPPORTED) {
-        if (!solve_fits_on_chip(d->n, d->n))
+        if (!solve_runs_without_workspace(d->n, d->n))
             return fail(ctx, MPCX_ERR_UNSUPPORTED, "c2d (no-allocation entry point): n = %d needs the blocked solver's device "
                         "workspace; use mpcx_c2d_backward_euler_f64_dev", d->n);
         const size_t need = (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n);

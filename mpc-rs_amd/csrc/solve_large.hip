@@ -19,7 +19,7 @@
 //
 // Kernels.  H is factored first, one workgroup per instance, and leaves per panel what a block of columns needs to
 // follow it: the multipliers (in place, in the panel's columns), the net row exchanges, L11^-1 and U11^-1.
-//   - up to 256 rows: lu_block_kernel, right-looking (after each panel the wavefronts sweep the trailing columns of H
+//   - up to 160 rows: lu_block_kernel, right-looking (after each panel the wavefronts sweep the trailing columns of H
 //     in the workspace);
 //   - beyond: lu_apply_kernel<..., FACTOR = true>, left-looking (column block j is loaded into LDS, the panels before
 //     it are applied with their multipliers streamed from the workspace, then it is factored and written back): H's
@@ -50,7 +50,14 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 constexpr int kNB = 16;
-constexpr int kSmallRows = 256;           // up to here H is factored right-looking by lu_block_kernel, beyond left-looking
+constexpr int kSmallRows = 256;           // the most rows lu_block_kernel (right-looking) takes
+#ifndef MPCX_LEFT_FROM
+#define MPCX_LEFT_FROM 160
+#endif
+// Systems of more (padded) rows than this are factored left-looking by lu_apply_kernel<..., true>: measured on 16 384
+// instances, solve only, right- against left-looking: 128 rows 7.4 / 7.7 ms, 160 rows 11.8 / 11.9 ms, 208 rows 22.4 / 18.1 ms,
+// 240 rows 32.2 / 23.0 ms (the right-looking sweeps move the trailing matrix through memory once per panel).
+constexpr int kLeftFrom = MPCX_LEFT_FROM;
 constexpr int kRhsMaxRows = 8 * 10 * kNB; // the widest variant of lu_apply_kernel: 8 wavefronts x 10 row tiles
 constexpr int kMaxTouched = 2 * kNB;
 
@@ -335,9 +342,9 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
     return true;
 }
 
-// Right-looking, for systems of up to kSmallRows rows: their time goes into the barriers of the panel factorization, and
-// a workgroup of 256 threads within 128 registers lets four instances share a CU.  (Larger systems are factored
-// left-looking by lu_apply_kernel<..., true>, which moves half the bytes.)
+// Right-looking, for systems of up to kSmallRows rows (used up to kLeftFrom): their time goes into the barriers of the
+// panel factorization, and a workgroup of 256 threads within 128 registers lets four instances share a CU.  (Larger
+// systems are factored left-looking by lu_apply_kernel<..., true>, which moves half the bytes.)
 constexpr int kThreads = 256, kWaves = kThreads / 64;
 __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
     extern __shared__ __align__(16) double sm[];
@@ -492,7 +499,7 @@ int rhs_ld(int nrp) { return (nrp % 32 == 0) ? nrp + 16 : nrp; }
 // later blocks need.  H's columns are read and written once; what is streamed per block are the multipliers of the
 // panels before it, half the bytes of a right-looking sweep over the trailing columns and reads only.
 template <int THREADS, int MT, bool FACTOR>
-__global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kernel(RhsArgs p) {  // at most 16 wavefronts (LDS slots)
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : 4) : 1) void lu_apply_kernel(RhsArgs p) {  // at most 16 wavefronts (LDS slots)
     extern __shared__ __align__(16) double sm[];
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -771,7 +778,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 4 : 1) void lu_apply_kern
 #ifdef MPCX_LU_STAMPS
             if (tid == 0) stamps[2] = (double)wall_clock64();
 #endif
-            if (!factor_block<THREADS, (kRhsMaxRows + THREADS - 1) / THREADS>(blk, ld, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv, gcol,
+            // (rows a thread holds: the variant serves at most NW MT tiles of 16 rows)
+            if (!factor_block<THREADS, (NW * MT * kNB + THREADS - 1) / THREADS>(blk, ld, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv, gcol,
                                        meta + (size_t)j * kMetaDoubles
 #ifdef MPCX_LU_STAMPS
                                        , p.X + (size_t)li * p.nr * p.nrhs + 4 * npan + 20 * j
@@ -856,10 +864,8 @@ int launch_apply(const RhsArgs &ra, size_t lds, hipStream_t s) {
 template <bool FACTOR>
 int launch_apply_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
     const int npan = ra.nrp / kNB;
-    if constexpr (!FACTOR) {  // (H of up to 256 rows is factored by lu_block_kernel)
-        if (npan <= 8) return launch_apply<256, 2, FACTOR>(ra, lds, s);
-        if (npan <= 16) return launch_apply<256, 4, FACTOR>(ra, lds, s);
-    }
+    if (npan <= 8) return launch_apply<256, 2, FACTOR>(ra, lds, s);
+    if (npan <= 16) return launch_apply<256, 4, FACTOR>(ra, lds, s);
     if (npan <= 32) return launch_apply<512, 4, FACTOR>(ra, lds, s);
     if (npan <= 56) return launch_apply<512, 7, FACTOR>(ra, lds, s);
     return launch_apply<512, 10, FACTOR>(ra, lds, s);
@@ -869,7 +875,7 @@ size_t rhs_lds_bytes(int nrp) {  // block, U12 / U11^-1, L11^-1, exchange lists,
     return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2 + 16) * sizeof(double) + sizeof(int) * (16 + kNB);
 }
 
-bool left_looking(int nrp) { return nrp > kSmallRows; }
+bool left_looking(int nrp) { return nrp > kLeftFrom; }
 
 size_t lu_lds_bytes(int nrp) {  // lu_block_kernel
     size_t d = (size_t)kNB * nrp + 2 * kNB * kNB + kWaves * kNB * kNB + kWaves;

@@ -129,14 +129,17 @@ def test_large_systems_blocked_solver(ctx, vm, m, fr, r, il):
     assert rel_fro(gain, want) <= 1e-11 * cond
 
 
-@pytest.mark.parametrize("vm", [96, 400])
+@pytest.mark.parametrize("vm", [48, 64, 96, 400])
 def test_large_singular_is_flagged(ctx, vm):
     rng = np.random.default_rng(8)
     batch = 4
     H = rng.standard_normal((batch, vm, vm)) + 10 * np.eye(vm)
     H[1, :, 40] = 0.0
-    if vm == 96:
-        H[2, 70, :] = H[2, 3, :]                      # two equal rows: an exactly zero pivot late in the elimination
+    if vm <= 64:
+        # two equal rows far apart: an exactly zero pivot late in the elimination, because both rows see the same
+        # operations in the same order -- the column-by-column kernels (up to 64 unknowns) share that with the reference's
+        # LU; the panel-wise solver treats a pivot row and an outside row differently and promises no exact zero here
+        H[2, vm - 9, :] = H[2, 3, :]
     else:
         H[2, vm - 30, :] = 0.0                        # a zero row stays zero through every update: the last pivot is exactly zero
     fv = rng.standard_normal((batch, vm))
