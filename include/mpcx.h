@@ -230,13 +230,15 @@ int mpcx_c2d_backward_euler_f64_dev(mpcx_ctx *ctx, const mpcx_dims *dims, const 
  * mpcx_c2d_backward_euler_f64_dev for callers that cannot allocate device memory while they run: code under HIP
  * graph capture, tight serving loops that re-discretise every tick, harnesses that forbid hipMalloc.  It has no
  * counterpart in the reference (the computation is model.rs:55-57, :138-140 as above).  Same arguments, same kernels and
- * bit-identical results; it never calls hipMalloc / hipFree or any allocating routine.  Its only scratch, I - Ac dt of
- * every instance, lives in a static device array of MPCX_C2D_NOALLOC_MAX_DOUBLES doubles (16 MiB on each GPU the
+ * bit-identical results; it never calls hipMalloc / hipFree or any allocating routine.  Its scratch -- I - Ac dt of
+ * every instance and, for systems beyond the one-wavefront solver kernels (n > 60 or so), the blocked solver's workspace
+ * behind it -- lives in a static device array of MPCX_C2D_NOALLOC_MAX_DOUBLES doubles (16 MiB on each GPU the
  * library runs on, held until the process ends), whose address on the context's device mpcx_create resolves.
- * Limits, reported as MPCX_ERR_UNSUPPORTED with a message: mpcx_array_elems(batch, interleave, n n) must not exceed
+ * Limits, reported as MPCX_ERR_UNSUPPORTED with a message: mpcx_array_elems(batch, interleave, n n), plus about
+ * (n + 15)^2 + 35 n doubles of solver workspace for one instance when n > 60, must not exceed
  * MPCX_C2D_NOALLOC_MAX_DOUBLES (plants the one-lane kernels take -- n <= 6 with m <= 2 -- need no scratch and have no
- * such limit), and n must be small enough for a solver that needs no workspace (n <= 100; from n = 64 on that is a plain
- * LDS kernel, several times slower than the workspace-backed solver of the _dev call).  All calls on one GPU share that GPU's
+ * such limit).  What is left behind the matrices decides how many instances one solver launch takes: a batch that
+ * nearly fills the array is solved in many small launches.  All calls on one GPU share that GPU's
  * array: two such calls that overlap in time on one device (different streams or contexts) race.
  */
 #define MPCX_C2D_NOALLOC_MAX_DOUBLES ((int64_t)1 << 21)

@@ -800,20 +800,26 @@ int mpcx_c2d_backward_euler_f64_noalloc_dev(mpcx_ctx *ctx, const mpcx_dims *d, c
     hipStream_t s = (hipStream_t)stream;
     rc = launch_c2d_lane(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, s);  // tiny plants: registers only, no scratch
     if (rc == MPCX_ERR_UNSUPPORTED) {
-        if (!solve_runs_without_workspace(d->n, d->n))
-            return fail(ctx, MPCX_ERR_UNSUPPORTED, "c2d (no-allocation entry point): n = %d needs the blocked solver's device "
-                        "workspace; use mpcx_c2d_backward_euler_f64_dev", d->n);
-        const size_t need = (size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n);
-        if (need > c2d_static_scratch_doubles())
-            return fail(ctx, MPCX_ERR_UNSUPPORTED, "c2d (no-allocation entry point): batch x n^2 = %zu doubles exceeds the static "
+        // the static scratch holds I - Ac dt of every instance and, behind it, the blocked solver's workspace for at least
+        // one instance when the system is beyond the one-wavefront kernels (fewer instances' worth means more launches)
+        const bool on_chip = solve_fits_on_chip(d->n, d->n);
+        if (!on_chip && !solve_large_supports(d->n))
+            return fail(ctx, MPCX_ERR_UNSUPPORTED, "c2d: n = %d is beyond what the solver holds on chip", d->n);
+        const size_t cap = c2d_static_scratch_doubles();
+        const size_t need = ((size_t)mpcx_array_elems(d->batch, d->interleave, (int64_t)d->n * d->n) + 31) & ~(size_t)31;
+        const size_t per = on_chip ? 0 : solve_large_ws_doubles(d->n, d->n);
+        if (need + per > cap)
+            return fail(ctx, MPCX_ERR_UNSUPPORTED, "c2d (no-allocation entry point): batch x n^2 = %zu doubles%s exceeds the static "
                         "scratch of %zu doubles; split the batch or use mpcx_c2d_backward_euler_f64_dev", need,
-                        c2d_static_scratch_doubles());
+                        on_chip ? "" : " plus one instance of solver workspace", cap);
         double *tmp = nullptr;
         rc = c2d_static_scratch(ctx->device, &tmp);
         if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "c2d (no-allocation entry point): device index %d is beyond the table", ctx->device);
         if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "hipGetSymbolAddress(mpcx_c2d_scratch)");
-        // every element of the scratch that the solver reads is written first by this call: nothing to clear
-        rc = launch_c2d_general(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, tmp, nullptr, 0, s);
+        // every element of the scratch that the solver reads is written first by this call (the blocked solver packs its
+        // matrices and clears its failure flags itself): nothing to clear here
+        rc = launch_c2d_general(Ac, Bc, dt, A, B, info, d->batch, W, d->n, d->m, tmp, on_chip ? nullptr : tmp + need,
+                                on_chip ? 0 : cap - need, s);
     }
     if (rc == MPCX_ERR_UNSUPPORTED) return fail(ctx, rc, "c2d: n = %d is beyond what the solver holds on chip", d->n);
     if (rc != 0) return hip_fail(ctx, (hipError_t)rc, "c2d launch");

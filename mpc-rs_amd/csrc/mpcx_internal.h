@@ -81,7 +81,6 @@ int c2d_static_scratch(int device, double **ptr);
 int launch_plants(int kind, const double *params, double dt, double *A, double *B, double *C, int *info, long long batch,
                   long long W, hipStream_t s);
 bool solve_fits_on_chip(int nr, int nrhs);            // a one-wavefront register/LDS kernel takes it (up to 64 unknowns)
-bool solve_runs_without_workspace(int nr, int nrhs);  // ... or, given no workspace, the plain LDS kernel does
 int launch_qp_gain_dense(const double *H, const double *Gamma, const double *W4, double *gain, int *info, long long batch,
                          long long W, int m, int r, int f, int v, double *ws, size_t ws_doubles, hipStream_t s);
 size_t solve_large_ws_doubles(int nr, int nrhs);

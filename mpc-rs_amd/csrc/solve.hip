@@ -540,7 +540,7 @@ int launch_solve(const SolveArgs &a, hipStream_t s) {
 
 // The plain one-wavefront kernel with the whole system in LDS.  The blocked solver is several times faster at every size
 // (64 unknowns x 192 right-hand sides: 5.8 against 108 ms for 16 384 instances), so this is only the last resort for what
-// the blocked solver refuses (a weight block wider than it serves).  Takes a ready right-hand side.
+// the blocked solver refuses (a weight block wider than it serves, a workspace too small for one instance).  Takes a ready right-hand side.
 int launch_solve_general(const SolveArgs &a, hipStream_t s) {
     if (a.Q) return MPCX_ERR_UNSUPPORTED;
     const int ld = a.nrow | 1;
@@ -562,12 +562,6 @@ bool solve_fits_on_chip(int nr, int nrhs) {
     int ldr = nr + nrhs + 1;
     while ((ldr & 3) != 2) ++ldr;
     return nr <= kSmallMaxRows && (size_t)nr * ldr * sizeof(double) <= 64 * 1024;
-}
-
-// True when a solve runs without the blocked solver's device workspace: one of the kernels above or, failing those, the
-// plain LDS kernel (which launch_solve_inplace / launch_qp_solve reach when they are given no workspace).
-bool solve_runs_without_workspace(int nr, int nrhs) {
-    return solve_fits_on_chip(nr, nrhs) || (size_t)(nr | 1) * (nr + nrhs) * sizeof(double) <= 160 * 1024;
 }
 
 int launch_qp_solve(const double *H, const double *fvec, double *u_seq, int *info, long long batch, long long W, int vm,

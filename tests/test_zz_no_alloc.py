@@ -37,7 +37,8 @@ def _run(ctx, entry, Ac, Bc, dt, il):
 def test_noalloc_c2d_matches_existing_entry_point_twice(ctx, il):
     rng = np.random.default_rng(77 + il)
     # general-n path (static scratch): a larger call, then a smaller one with another shape, then a lane-kernel shape
-    for batch, n, m in ((700, 12, 4), (90, 9, 2), (33, 40, 3), (300, 4, 1)):
+    # and two systems beyond the one-wavefront solver kernels (the blocked solver, its workspace behind the matrices)
+    for batch, n, m in ((700, 12, 4), (90, 9, 2), (33, 40, 3), (300, 4, 1), (150, 80, 3), (9, 120, 2)):
         Ac, Bc = _plants(rng, batch, n, m)
         Ac[batch // 2] = 0.0
         Ac[batch // 2, 0, 0] = 4.0  # dt = 0.25: I - Ac dt has an exactly zero first row and column (fused or not): flagged, NaN outputs
@@ -63,11 +64,16 @@ def test_noalloc_c2d_limits(ctx):
     with pytest.raises(ffi.MpcxError) as ei:
         ctx.c2d_noalloc_dev(d, z.data_ptr(), z.data_ptr(), 0.01, z.data_ptr(), z.data_ptr(), None, 0)
     assert ei.value.code == ffi.ERR_UNSUPPORTED and "static scratch" in ei.value.message
-    # beyond the on-chip solver: rejected
-    d = ffi.make_dims(150, 1, 1, 1, 1, 2, 0, 1)
+    # beyond the solver: rejected
+    d = ffi.make_dims(1300, 1, 1, 1, 1, 1, 0, 1)
     with pytest.raises(ffi.MpcxError) as ei:
         ctx.c2d_noalloc_dev(d, z.data_ptr(), z.data_ptr(), 0.01, z.data_ptr(), z.data_ptr(), None, 0)
     assert ei.value.code == ffi.ERR_UNSUPPORTED
+    # matrices that fit, but no room behind them for one instance of the blocked solver's workspace: rejected
+    d = ffi.make_dims(80, 1, 1, 1, 1, (1 << 21) // 6400, 0, 1)
+    with pytest.raises(ffi.MpcxError) as ei:
+        ctx.c2d_noalloc_dev(d, z.data_ptr(), z.data_ptr(), 0.01, z.data_ptr(), z.data_ptr(), None, 0)
+    assert ei.value.code == ffi.ERR_UNSUPPORTED and "solver workspace" in ei.value.message
     # exactly at the limit is accepted
     batch = (1 << 21) // (n * n)
     rng = np.random.default_rng(3)
