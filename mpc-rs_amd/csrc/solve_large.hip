@@ -21,14 +21,18 @@
 // follow it: the multipliers (in place, in the panel's columns), the net row exchanges, L11^-1 and U11^-1.
 //   - up to 160 rows: lu_block_kernel, right-looking (after each panel the wavefronts sweep the trailing columns of H
 //     in the workspace);
-//   - beyond: lu_apply_kernel<..., FACTOR = true>, left-looking (column block j is loaded into LDS, the panels before
-//     it are applied with their multipliers streamed from the workspace, then it is factored and written back): H's
+//   - beyond: lu_applyr_kernel<..., FACTOR = true>, left-looking (column block j is loaded, the panels before it are
+//     applied with their multipliers streamed from the workspace, then it is factored in LDS and written back): H's
 //     columns are read and written once, and the streamed multipliers are half the bytes of the trailing sweeps.
-// lu_apply_kernel<..., false> then gives every block of 16 right-hand-side columns to a workgroup of its own, which
-// keeps the block in LDS through all panels, applies U11^-1 and writes the result in the caller's layout.  The block is
-// formed from the caller's arrays as it is loaded (Gamma^T blockdiag(Q) included), so a right-hand side is read once
-// and its solution written once, and never enters the workspace; the workgroups of one instance run on one XCD and
-// read the same multipliers at about the same time (L2 hits).
+// lu_applyr_kernel<..., false> then gives every block of 16 right-hand-side columns to a workgroup of its own, which
+// applies all panels to it, then U11^-1, and writes the result in the caller's layout.  The block is formed from the
+// caller's arrays as it is loaded (Gamma^T blockdiag(Q) included), so a right-hand side is read once and its solution
+// written once, and never enters the workspace; the workgroups of one instance run on one XCD and read the same
+// multipliers at about the same time (L2 hits).
+// While panels are applied the block lives in the wavefronts' accumulator registers (lu_applyr_kernel; only the rows a
+// panel's exchanges touch pass through LDS).  lu_apply_kernel, which keeps the block in LDS and moves every tile
+// through it at every step, is the older form of the same kernel: built with -DMPCX_APPLY_LDS for comparison (same
+// results bit for bit; 3-5 % slower on 208- and 800-row systems).
 #include <type_traits>
 #include <utility>
 
@@ -66,14 +70,19 @@ struct LuArgs {
     int *failed;     // per instance
     long long count; // instances in this launch
     int nrp;
-    double *meta;    // per instance and panel: L11^-1 and U11^-1 (256 doubles each), then tcount, trow[32], tsrc[32] as ints (kMetaDoubles in all)
+    double *meta;    // per instance and panel: L11^-1 and U11^-1 (256 doubles each), then the exchanges as ints (kMetaDoubles in all)
 #ifdef MPCX_LU_STAMPS
     double *dbg;     // diagnostic build: per instance the time spent loading panels, factoring them, sweeping the trailing columns
     long long dbg_stride;
 #endif
 };
 constexpr int kMetaInts = 2 * kNB * kNB;                               // where the ints start, in doubles
-constexpr int kMetaDoubles = kMetaInts + (2 * kMaxTouched + 16) / 2;  // 512 + 40
+// a panel's exchanges as ints: tcount, trow[32], tsrc[32], then for a block that keeps the touched rows' old content as a
+// list: tsl[16] (where in the list each pivot row's source lies), the same packed four to an int in the order the
+// matrix-core operand wants them, and per outside row its table entry (or -1)
+constexpr int kTslAt = 1 + 2 * kMaxTouched, kAtpAt = kTslAt + kNB, kEntAt = kAtpAt + 4;
+constexpr int kTmetaInts = kEntAt + kNB + 3;                           // (+ 3: what follows stays 8-byte aligned)
+constexpr int kMetaDoubles = kMetaInts + kTmetaInts / 2;               // 512 + 52
 
 // ---- pack: workspace <- H padded with an identity block ----
 struct PackArgs {
@@ -140,7 +149,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
                                           ) {
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int *tcount = tmeta, *trow = tmeta + 1, *tsrc = tmeta + 1 + kMaxTouched;
+    int *tcount = tmeta, *trow = tmeta + 1, *tsrc = tmeta + 1 + kMaxTouched, *tsl = tmeta + kTslAt;
     // The panel column by column: pivot searched among the rows at positions >= k0 + jc, every row outside the pivot
     // block reduced.  A thread keeps its rows (RPT of them, 16 entries each) in registers for all 16 columns; a row
     // never moves, its POSITION does (an exchange swaps two positions), and the rows go back to LDS at their final
@@ -315,6 +324,18 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
         }
         if (lane < kMaxTouched) { trow[lane] = row; tsrc[lane] = src; }
         if (lane == 0) *tcount = nt;
+        // Where a block that keeps the old content of the touched rows as a list (the pivot block's 16 rows, then the rows
+        // outside it in the order of this description) finds the source of pivot row `lane`: its index in that list.
+        int at = src - k0;
+        for (int j = kNB; j < nt; ++j) {
+            const int rj = __shfl(row, j);
+            if (rj == src) at = j;
+        }
+        if (lane < kNB) tsl[lane] = at;
+        const int packed = __shfl(at, lane & 3) | (__shfl(at, (lane & 3) + 4) << 8) | (__shfl(at, (lane & 3) + 8) << 16) | (__shfl(at, (lane & 3) + 12) << 24);
+        if (lane < 4) tmeta[kAtpAt + lane] = packed;  // [k = lane + 4 q] in byte q
+        const int osrc = __shfl(src, kNB + (lane & 15));
+        if (lane < kNB) tmeta[kEntAt + lane] = kNB + lane < nt ? ((osrc - k0) | (lane << 8)) : -1;  // outside row `lane`: the pivot-block row it receives, its place in the list
     }
     __syncthreads();
     FSTAMP(18);
@@ -337,7 +358,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
         }
     }
     if (tid < kNB * kNB) { mt[tid] = linv[tid]; mt[kNB * kNB + tid] = uinv[tid]; }
-    if (tid < 1 + 2 * kMaxTouched) ((int *)(mt + kMetaInts))[tid] = tmeta[tid];
+    if (tid < kEntAt + kNB) ((int *)(mt + kMetaInts))[tid] = tmeta[tid];
     FSTAMP(19);
     return true;
 }
@@ -483,7 +504,7 @@ struct RhsArgs {
     int nr, nrhs, r, nrp, negate, ld;
 };
 #ifndef MPCX_RHS_ABLATE
-#define MPCX_RHS_ABLATE 0  // experiments only (wrong results): 1 no block load, 2 no panels, 4 no tile updates, 8 no U11 step, 16 no write
+#define MPCX_RHS_ABLATE 0  // experiments only (wrong results): 1 no block load, 2 no panels, 4 no tile updates, 8 no U11 step, 16 no write, 64 every multiplier request to the same tile
 #endif
 constexpr int kMaxWeightBlock = 64;  // widest output weight block r served
 
@@ -504,6 +525,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : 4) : 1) voi
     constexpr int NW = THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wvs = __builtin_amdgcn_readfirstlane(wv);  // the same number in a scalar register: conditions on it are branches, not masks
+    // Row tiles are dealt to the wavefronts round-robin, starting at a wavefront that differs from workgroup to workgroup:
+    // the tiles seldom divide evenly (13 over 4 wavefronts), wavefront i of every workgroup sits on SIMD i, and the step is
+    // bound by the matrix pipe of the busiest SIMD -- without the rotation that is always the same one.
+#ifndef MPCX_NO_TILE_ROTATION
+    const int wr = (wvs + (int)(blockIdx.x >> 3)) & (NW - 1);
+#else
+    const int wr = wvs;
+#endif
     const int nrp = p.nrp, ld = p.ld, npan = nrp / kNB, nblk = (p.nrhs + kNB - 1) / kNB;
     // Workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (instance, block) pairs, so
     // that the blocks of one instance, which read the same multipliers, share one L2.
@@ -544,7 +573,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : 4) : 1) voi
     // per step the compiler can wait for "all but the loads issued since" when a multiplier is first used; behind a
     // condition it cannot, and waits for every outstanding load.
     auto fetch_one = [&](int pn, int u, int q) __attribute__((always_inline)) {
-        const int t0 = wvs + NW * u, t = t0 < npan ? t0 : npan - 1;
+        const int t0 = wr + NW * u, t = t0 < npan ? t0 : npan - 1;
+        if (MPCX_RHS_ABLATE & 64) return A[(unsigned)(lofs + 4 * q * nrp)];  // (every request hits the same 2 KB)
         return A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
     };
     auto fetch_tile = [&](int pn, int u, double(&dst)[4]) __attribute__((always_inline)) {
@@ -658,6 +688,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : 4) : 1) voi
 #else
 #define RSTAMP(k) do {} while (0)
 #endif
+    d4 acc_keep[MT] = {};
     auto panel_step = [&](int pn, int upto) __attribute__((always_inline)) {
         if ((MPCX_RHS_ABLATE & 2) && pn >= 0) return;
         // (The barriers of a step order LDS traffic only: a __syncthreads() would also wait for the multipliers that were
@@ -705,40 +736,86 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : 4) : 1) voi
 #pragma unroll
         for (int q = 0; q < 4; ++q) nu[q] = -u12s[(kq + 4 * q) * kNB + l15];
         const int cofs = kq * ld + l15;  // + 4 q columns, + r0
-        // Straight-line code, the same for every tile slot: a slot past the last tile, or the panel's own tile, works on
-        // the last tile / on itself and does not write the result back.  Every tile of the wavefront is read before the
-        // first product (one LDS round trip per step, not one per tile).
-        d4 acc[MT];
+        // The same loads for every tile slot: a slot past the last tile, or the panel's own tile, requests the last tile's /
+        // its own multipliers and drops them, so that the number of loads in flight does not depend on the path taken; its
+        // products and its write-back are skipped (a branch: the condition is uniform over the wavefront).  Every tile of
+        // the wavefront is read before the first product (one LDS round trip per step, not one per tile).
+        d4 (&acc)[MT] = acc_keep;
+        if (!(MPCX_RHS_ABLATE & 128)) {  // (128: the tiles stay in registers from step to step, no LDS traffic for them)
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            const int t0 = wvs + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
+            const int t0 = wr + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[u][q] = blk[cofs + 4 * q * ld + r0];
         }
+        }
+#ifdef MPCX_TILE_AFTER_TILE
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            const int t0 = wvs + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
+            const int t0 = wr + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
             const bool live = t0 < npan && t0 != pn && !(MPCX_RHS_ABLATE & 4);  // uniform over the wavefront
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb[u][q], acc[u], 0, 0, 0);
-            fetch_tile(pf, u, lb[u]);
             if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb[u][q], acc[u], 0, 0, 0);
+            }
+            fetch_tile(pf, u, lb[u]);
+            if (live && !(MPCX_RHS_ABLATE & 128)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) blk[cofs + 4 * q * ld + r0] = acc[u][q];
             }
         }
+#else
+        // A tile's four products form a dependent chain (each waits for the one before: about twice the issue interval), so
+        // the products go quarter by quarter of the contraction, the wavefront's tiles side by side; each multiplier is
+        // requested again, for the next panel, right behind the product that used it.  The order is pinned: left to itself
+        // the scheduler gathers the requests into bursts and the waits stop counting.
+        bool live[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const int t0 = wr + NW * u;
+            live[u] = t0 < npan && t0 != pn && !(MPCX_RHS_ABLATE & 4);  // uniform over the wavefront
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int u = 0; u < MT; ++u) {
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb[u][q], acc[u], 0, 0, 0);
+                lb[u][q] = fetch_one(pf, u, q);
+                __builtin_amdgcn_sched_barrier(7);  // (scalar and vector arithmetic may cross, matrix and memory instructions may not)
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const int t0 = wr + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
+            if (live[u]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) blk[cofs + 4 * q * ld + r0] = acc[u][q];
+            }
+        }
+#endif
         RSTAMP(4);
     };
     // the panels [0, upto) applied to the block in LDS
     auto apply_panels = [&](int upto) __attribute__((always_inline)) {
         if (upto <= 0) return;
         fetch_meta(0);
+#ifdef MPCX_TILE_AFTER_TILE
 #pragma unroll
         for (int u = 0; u < MT; ++u) fetch_tile(0, u, lb[u]);
+#else
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // (in the order the steps re-request them)
+#pragma unroll
+            for (int u = 0; u < MT; ++u) {
+                lb[u][q] = fetch_one(0, u, q);
+                __builtin_amdgcn_sched_barrier(7);
+            }
+        }
+#endif
         for (int pn = 0; pn < upto; ++pn) panel_step(pn, upto);
     };
     if constexpr (FACTOR) {
-        double *red_val = (double *)(tmeta + 2 * kMaxTouched + 4);  // [NW]
+        double *red_val = (double *)(tmeta + kTmetaInts);  // [NW]
         int *red_idx = (int *)(red_val + NW);                       // [NW]
         int *ipiv = red_idx + NW;                                   // [16]
         double *uinv = u12s;
@@ -849,14 +926,360 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : 4) : 1) voi
 #endif
 }
 
+
+// ---- the same with the block in registers ----
+// A block of 16 columns is 2 KB per 16-row tile: a wavefront keeps its tiles in its accumulator registers (lane
+// (kq, l15) holds columns kq + 4 q of row l15, the layout the products leave them in) through all the panels, and only
+// the rows a panel's exchanges touch travel through LDS -- the 16 rows of the pivot block and the rows outside it that
+// trade places with them, 32 at most -- instead of every tile being read from and written back to LDS at every step
+// (with the tiles in LDS the steps were bound by LDS bandwidth: 2 x 103 KB per step and workgroup at 800 rows).
+//
+// Per step: (A) the owner of the pivot block's tile and the owners of touched outside rows put those rows' old content
+// into the list old[0..15] / old[16..]; a table row -> (pivot-block row it receives, place in the list) tells a lane
+// whether its row is touched, the first wavefront keeps it current one panel ahead; (barrier) the first wavefront forms
+// U12 = L11^-1 T from the list (the panel's description says where in the list each pivot row's source lies);
+// (barrier) the pivot block's tile becomes U12, a touched outside row takes the old content of the pivot-block row the
+// table names, every other tile gets its rank-16 update.  The list is double-buffered by the step's parity: a fast
+// wavefront may already publish rows of the next step while a slow one still reads this step's.
+constexpr int kTS = kNB + 1;  // row stride of a 16 x 16 tile staged in LDS (an odd stride: rows and columns both spread over the banks)
+
+#ifndef MPCX_RHS_WGS
+#define MPCX_RHS_WGS 3  // workgroups of 256 threads per CU for the right-hand sides: three leave each thread 168 registers (measured 52.9 against 56.7 ms with four)
+#endif
+template <int THREADS, int MT, bool FACTOR>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : MPCX_RHS_WGS) : 1) void lu_applyr_kernel(RhsArgs p) {
+    extern __shared__ __align__(16) double sm[];
+    constexpr int NW = THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const int wr = (wvs + (int)(blockIdx.x >> 3)) & (NW - 1);  // first tile of this wavefront (rotated from workgroup to workgroup)
+    const int nrp = p.nrp, ld = p.ld, npan = nrp / kNB, nblk = (p.nrhs + kNB - 1) / kNB;
+    const long long per_xcd = (p.total + 7) / 8;
+    const long long item = FACTOR ? (long long)blockIdx.x : (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (!FACTOR && ((blockIdx.x >> 3) >= per_xcd || item >= p.total)) return;
+    const long long li = FACTOR ? item : item / nblk;
+    const int bk = FACTOR ? 0 : (int)(item - li * nblk), c0 = bk * kNB;
+    const long long b = p.first + li;
+    double *A = p.ws + (size_t)li * nrp * nrp;
+    // LDS: L11^-1; with FACTOR what the panel factorisation needs beside its block; then the step's buffers -- which the
+    // block being factored overlays (it is in registers while the panels are applied and in LDS while it is factored).
+    double *linv = sm;                                           // [16][16]
+    double *uinv = linv + kNB * kNB;                             // FACTOR: [16][16]
+    int *tmeta = (int *)(uinv + kNB * kNB);                      // FACTOR: a panel's exchange lists as factor_block leaves them
+    double *red_val = (double *)(tmeta + kTmetaInts);            // FACTOR: [NW]
+    int *red_idx = (int *)(red_val + NW);                        // FACTOR: [NW]
+    int *ipiv = red_idx + NW;                                    // FACTOR: [16]
+    double *old = FACTOR ? (double *)(ipiv + kNB) : linv + kNB * kNB;  // [2][32][kTS]
+    double *blk = old;                                           // FACTOR: [16][ld], over the step's buffers
+    double *u12s = old + 2 * kMaxTouched * kTS;                  // [16][kTS]: U12[row][column]
+    double *xp = u12s + kNB * kTS;                               // right-hand sides: [NW][16][kTS], a wavefront's own tile for transposing
+    int *table = (int *)(xp + (FACTOR ? 0 : NW * kNB * kTS));    // [2][nrp], by the panel's parity
+    const bool bad = !FACTOR && p.failed[li] != 0;
+    if (!FACTOR && p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
+    const long long ER = (long long)p.nr * p.nrhs;
+    if (bad) {  // uniform over the workgroup
+        for (int e = tid; e < kNB * p.nr; e += THREADS) {
+            const int c = e / p.nr, row = e - c * p.nr;
+            if (c0 + c < p.nrhs) p.X[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+        return;
+    }
+    const int kq = lane >> 4, l15 = lane & 15;
+    const int lofs = kq * nrp + l15;
+    double *meta = p.meta + (size_t)li * npan * kMetaDoubles;
+    d4 acc[MT];
+    double lb[MT][4];
+    int tile0[MT];    // first row of the slot's tile (a slot past the last tile: the last tile, never written)
+    bool owned[MT];   // the slot holds a tile
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+        const int t0 = wr + NW * u;
+        owned[u] = t0 < npan;
+        tile0[u] = (t0 < npan ? t0 : npan - 1) * kNB;
+    }
+    auto fetch_one = [&](int pn, int u, int q) __attribute__((always_inline)) {
+        return A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + tile0[u])];
+    };
+    auto fetch_tile = [&](int pn, int u, double(&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = fetch_one(pn, u, q);
+    };
+    // A panel's exchanges as the first wavefront uses them (every wavefront requests them, unconditionally and one panel
+    // ahead like the multipliers, so that the waits stay counted): where in the list the 16 pivot rows' sources lie
+    // (operand layout [k = kq + 4 q], a byte each) and, one outside row per lane l15, the row and its table entry.
+    int l_atp = 0, l_ent = -1, l_row = 0, at_cur = 0;
+    auto fetch_lists = [&](int pn) __attribute__((always_inline)) {
+        const int *mi = (const int *)(meta + (size_t)pn * kMetaDoubles + kMetaInts);
+        l_atp = mi[kAtpAt + kq];
+        l_ent = mi[kEntAt + l15];
+        l_row = mi[1 + kNB + l15];
+    };
+    double m_linv = 0.0;
+    auto fetch_linv = [&](int pn) __attribute__((always_inline)) {  // (every thread, the upper half of a larger workgroup for nothing: no request behind a condition)
+        m_linv = meta[(size_t)pn * kMetaDoubles + (tid & (kNB * kNB - 1))];
+    };
+    auto panel_step = [&](int pn, int upto) __attribute__((always_inline)) {
+        double *ob = old + (pn & 1) * (kMaxTouched * kTS);
+        int *tab = table + (pn & 1) * nrp, *tab_next = table + ((pn + 1) & 1) * nrp;
+        // (A) which of this wavefront's rows the panel touches (the entry is cleared by the lane that read it: the table
+        // of this parity is clean again when the first wavefront fills it for the panel after the next); their old
+        // content into the list
+        int s[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) s[u] = tab[tile0[u] + l15];
+        if (tid < kNB * kNB) linv[tid] = m_linv;
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const bool mine = owned[u] && tile0[u] == pn * kNB;  // uniform over the wavefront
+            if (!owned[u]) s[u] = -1;
+            const bool any = __builtin_amdgcn_ballot_w64(s[u] >= 0) != 0;
+            if (mine || any) {
+                const int at = mine ? l15 : kNB + (s[u] >> 8);
+                if (mine || s[u] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ob[at * kTS + kq + 4 * q] = acc[u][q];
+                }
+                if (s[u] >= 0 && kq == 0) tab[tile0[u] + l15] = -1;
+            }
+        }
+        lds_barrier();
+        if (wvs == 0) {
+            double la[4], tb[4];
+            int li2 = l15, ki = kq;
+            asm volatile("" : "+v"(li2), "+v"(ki));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                la[q] = linv[li2 * kNB + ki + 4 * q];                         // A operand: L11^-1[i = l15][k = kq + 4 q]
+                tb[q] = ob[((at_cur >> (8 * q)) & 255) * kTS + li2];          // B operand: T[k = kq + 4 q][column l15]
+            }
+            d4 u12 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u12 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], tb[q], u12, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u12s[(ki + 4 * q) * kTS + li2] = u12[q];  // D[i = kq + 4 q][column l15]
+            // the next panel's touched outside rows into the table of the other parity (lanes 0..15, one row each)
+            if (lane < kNB && pn + 1 < upto && l_ent >= 0) tab_next[l_row] = l_ent;
+        }
+        at_cur = l_atp;
+        fetch_lists(pn + 2 < upto ? pn + 2 : upto - 1);
+        const int pf = pn + 1 < upto ? pn + 1 : pn;
+        fetch_linv(pf);
+        lds_barrier();
+        d4 nu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nu[q] = -u12s[(kq + 4 * q) * kTS + l15];
+        // touched rows take their new content: the pivot block's tile becomes U12, an outside row the old content of the
+        // pivot-block row the table names (loads under a uniform branch, the choice per lane)
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const bool mine = owned[u] && tile0[u] == pn * kNB;
+            const bool any = __builtin_amdgcn_ballot_w64(s[u] >= 0) != 0;
+            if (mine || any) {
+                double nv[4];
+                const double *from = mine ? u12s + l15 * kTS : ob + ((s[u] >= 0 ? s[u] : 0) & 255) * kTS;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nv[q] = from[kq + 4 * q];
+                const bool take = mine || s[u] >= 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[u][q] = take ? nv[q] : acc[u][q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const bool live = owned[u] && tile0[u] != pn * kNB;  // uniform over the wavefront
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb[u][q], acc[u], 0, 0, 0);
+            }
+            fetch_tile(pf, u, lb[u]);
+        }
+    };
+    // the panels [0, upto) applied to the block in the accumulators
+    auto apply_panels = [&](int upto) __attribute__((always_inline)) {
+        if (upto <= 0) return;
+        // (the requests in the order the steps issue them: the waits are counted against the order of issue, and a different
+        // order on the way into the loop makes the first wait of every step cover nearly everything in flight)
+        fetch_lists(0);
+        for (int e = tid; e < 2 * nrp; e += THREADS) table[e] = -1;
+        lds_barrier();
+        if (wvs == 0 && lane < kNB && l_ent >= 0) table[l_row] = l_ent;
+        at_cur = l_atp;
+        fetch_lists(upto > 1 ? 1 : 0);
+        fetch_linv(0);
+        lds_barrier();  // the tables (cleared by everyone, the first panel's entries set) before the first look-up
+#pragma unroll
+        for (int u = 0; u < MT; ++u) fetch_tile(0, u, lb[u]);
+        for (int pn = 0; pn < upto; ++pn) panel_step(pn, upto);
+    };
+
+    if constexpr (FACTOR) {
+        for (int j = 0; j < npan; ++j) {
+            const int k0 = j * kNB;
+            double *gcol = A + (size_t)k0 * nrp;
+#pragma unroll
+            for (int u = 0; u < MT; ++u) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[u][q] = gcol[(size_t)(kq + 4 * q) * nrp + tile0[u] + l15];
+            }
+            apply_panels(j);
+            __syncthreads();  // the last step's buffers are read no more: the block takes their place
+#pragma unroll
+            for (int u = 0; u < MT; ++u) {
+                if (owned[u]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) blk[(kq + 4 * q) * ld + tile0[u] + l15] = acc[u][q];
+                }
+            }
+            __syncthreads();
+            if (!factor_block<THREADS, (NW * MT * kNB + THREADS - 1) / THREADS>(blk, ld, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv, gcol,
+                                       meta + (size_t)j * kMetaDoubles
+#ifdef MPCX_LU_STAMPS
+                                       , nullptr
+#endif
+                                       )) {
+                if (tid == 0) p.failed[li] = 1;
+                return;
+            }
+            __syncthreads();  // (workgroup scope is all the ordering the next block's reads of this panel need)
+        }
+        return;
+    }
+
+    // The block: 16 columns of the right-hand side, rows beyond nr and columns beyond nrhs zero, straight into the
+    // accumulators' layout.
+    if (p.Q == nullptr) {
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = tile0[u] + l15, c = c0 + kq + 4 * q;
+                acc[u][q] = (owned[u] && row < p.nr && c < p.nrhs) ? p.R[elem_index(b, (long long)c * p.nr + row, ER, p.W)] : 0.0;
+            }
+        }
+    } else {
+        // Gamma^T blockdiag(Q) (controller.rs:96, M^T W4): column c = g r + a2, row k is sum_a Gamma[g r + a][k] Q[a2][a]
+        // (Q stored column-major: Q[a2 * r + a]).  The block's 16 columns touch the rows [lo, hi) of Gamma, a contiguous
+        // run per unknown k of the column-major (f r) x (v m) array.  Per tile of 16 unknowns the block is the product
+        // D[column][unknown] = sum_j S[column][j] Gamma[lo + j][unknown], S the selection of Q's entries (zero where row
+        // lo + j lies outside the column's weight block): on the matrix cores, Gamma read straight from memory.
+        const int r = p.r, lo = (c0 / r) * r;
+        int hi = ((c0 + kNB - 1) / r + 1) * r;
+        if (hi > p.nrhs) hi = p.nrhs;
+        const int w = hi - lo, ns = (w + 3) / 4;
+        const bool q_lds = r * r <= kNB * kNB;  // the weight block rides in LDS (the U12 buffer is idle until the panels start)
+        if (q_lds) {
+            for (int e = tid; e < r * r; e += THREADS) u12s[e] = p.Q[e];
+            __syncthreads();
+        }
+        const double *qw = q_lds ? u12s : p.Q;
+        const int cc = c0 + l15, g = cc / r, a2 = cc - g * r, joff = lo - g * r;  // A operand: column lane & 15
+        if (ns <= 6) {
+            // (the usual case: the 16 columns touch at most 24 rows of Gamma)  Four tiles of a wavefront at a time, every
+            // load of the four issued before the first product: one memory latency per four tiles.
+            constexpr int TB = 4, NS = 6;
+            double qa[NS];
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const int jj = 4 * u + kq, ja = jj + joff;
+                qa[u] = (cc < p.nrhs && jj < w && ja >= 0 && ja < r) ? qw[a2 * r + ja] : 0.0;
+            }
+            static_for<(MT + TB - 1) / TB>([&](auto rb) {
+                constexpr int u0 = decltype(rb)::value * TB, UN = MT - u0 < TB ? MT - u0 : TB;
+                double gb[UN][NS];
+#pragma unroll
+                for (int i = 0; i < UN; ++i) {
+                    const int k = tile0[u0 + i] + l15;  // B operand: unknown lane & 15
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) {
+                        const int jj = 4 * u + kq;
+                        gb[i][u] = (owned[u0 + i] && k < p.nr && jj < w) ? p.R[elem_index(b, (long long)k * p.nrhs + lo + jj, ER, p.W)] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < UN; ++i) {
+                    d4 a = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) a = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[u], gb[i][u], a, 0, 0, 0);  // (zeros past w)
+                    acc[u0 + i] = a;
+                }
+            });
+        } else {
+            constexpr int SC = 12;  // steps of four rows of Gamma in flight per tile
+#pragma unroll
+            for (int u = 0; u < MT; ++u) {
+                const int k = tile0[u] + l15;  // B operand: unknown lane & 15
+                d4 a = {0.0, 0.0, 0.0, 0.0};
+                for (int s0 = 0; s0 < ns; s0 += SC) {
+                    double gb[SC], qa[SC];
+#pragma unroll
+                    for (int i = 0; i < SC; ++i) {
+                        const int jj = 4 * (s0 + i) + kq, ja = jj + joff;
+                        gb[i] = (owned[u] && k < p.nr && jj < w) ? p.R[elem_index(b, (long long)k * p.nrhs + lo + jj, ER, p.W)] : 0.0;
+                        qa[i] = (cc < p.nrhs && jj < w && ja >= 0 && ja < r) ? qw[a2 * r + ja] : 0.0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < SC; ++i)
+                        if (s0 + i < ns) a = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[i], gb[i], a, 0, 0, 0);
+                }
+                acc[u] = a;
+            }
+        }
+        __syncthreads();  // the weight block leaves the U12 buffer
+    }
+    apply_panels(npan);
+    // x_p = U11_p^-1 y_p per tile, where it lies: X^T = Y^T U11^-T needs the tile transposed as its first operand -- through
+    // the wavefront's own LDS tile (no barrier: a wavefront's LDS operations execute in order).  Every inverse is
+    // requested before the first product (the multipliers' registers are free now).
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+        const double *ui = meta + (size_t)(tile0[u] / kNB) * kMetaDoubles + kNB * kNB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lb[u][q] = ui[l15 * kNB + kq + 4 * q];  // B operand: [k = kq + 4 q][row l15] = U11^-1[row l15][k]
+    }
+    double *mine = xp + wvs * (kNB * kTS);
+    const double sign = p.negate ? -1.0 : 1.0;
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+        if (owned[u]) {
+            double ya[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mine[l15 * kTS + kq + 4 * q] = acc[u][q];       // [row][column]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ya[q] = mine[(kq + 4 * q) * kTS + l15];         // A operand: [column l15][k = row kq + 4 q]
+            d4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ya[q], lb[u][q], x, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // D[column kq + 4 q][row l15]
+                const int row = tile0[u] + l15, c = c0 + kq + 4 * q;
+                if (row < p.nr && c < p.nrhs) p.X[elem_index(b, (long long)c * p.nr + row, ER, p.W)] = sign * x[q];
+            }
+        }
+    }
+}
+
+size_t applyr_lds_bytes(int nrp, int nw, bool factor) {
+    const size_t step = (2 * kMaxTouched * kTS + kNB * kTS + (factor ? 0 : (size_t)nw * kNB * kTS)) * sizeof(double) + (size_t)2 * nrp * sizeof(int);
+    if (!factor) return kNB * kNB * sizeof(double) + step;
+    const size_t fixed = (2 * kNB * kNB + kTmetaInts / 2 + nw) * sizeof(double) + sizeof(int) * (nw + kNB);
+    const size_t block = (size_t)kNB * rhs_ld(nrp) * sizeof(double);
+    return fixed + (block > step ? block : step);
+}
+
 template <int THREADS, int MT, bool FACTOR>
 int launch_apply(const RhsArgs &ra, size_t lds, hipStream_t s) {
+#ifdef MPCX_APPLY_LDS  // the block in LDS (the older kernel, kept for comparison)
+    auto kernel = lu_apply_kernel<THREADS, MT, FACTOR>;
+#else
+    auto kernel = lu_applyr_kernel<THREADS, MT, FACTOR>;
+    lds = applyr_lds_bytes(ra.nrp, THREADS / 64, FACTOR);
+#endif
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)lu_apply_kernel<THREADS, MT, FACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     const long long grid = FACTOR ? ra.count : (ra.total + 7) / 8 * 8;
-    hipLaunchKernelGGL((lu_apply_kernel<THREADS, MT, FACTOR>), dim3((unsigned)grid), dim3(THREADS), lds, s, ra);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(THREADS), lds, s, ra);
     return 0;
 }
 
@@ -872,14 +1295,14 @@ int launch_apply_any(const RhsArgs &ra, size_t lds, hipStream_t s) {
 }
 
 size_t rhs_lds_bytes(int nrp) {  // block, U12 / U11^-1, L11^-1, exchange lists, then the panel factorization's reduction slots and pivots
-    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + (2 * kMaxTouched + 4) / 2 + 16) * sizeof(double) + sizeof(int) * (16 + kNB);
+    return ((size_t)kNB * rhs_ld(nrp) + 2 * kNB * kNB + kTmetaInts / 2 + 16) * sizeof(double) + sizeof(int) * (16 + kNB);
 }
 
 bool left_looking(int nrp) { return nrp > kLeftFrom; }
 
 size_t lu_lds_bytes(int nrp) {  // lu_block_kernel
     size_t d = (size_t)kNB * nrp + 2 * kNB * kNB + kWaves * kNB * kNB + kWaves;
-    return d * sizeof(double) + sizeof(int) * (kWaves + kNB + 2 * kMaxTouched + 4);
+    return d * sizeof(double) + sizeof(int) * (kWaves + kNB + kTmetaInts);
 }
 
 }  // namespace
