@@ -397,6 +397,8 @@ def main():
             res["lib_gather"] = lib_gather
         if mfma_ms is not None:
             res["roofline"] = _mfma_roofline(case, mfma_ms, kernel_ms, achieved)
+        if args.op in ("solve", "gain", "gain_rows"):
+            res["roofline"] = _solver_roofline(case, args.op, kernel_ms, res["roofline"])
         if args.op in ("solve", "gain", "gain_rows", "loop", "plants"):
             res["check"]["singular_instances"] = int((case.info != 0).sum().item())
         if world == 1 and not args.no_cpu_baseline and args.op in ("qp", "rollout"):
@@ -441,6 +443,8 @@ def main():
                     torch.cuda.synchronize()
                     rec["hessian_algo"] = 1
                     rec["roofline"] = _mfma_roofline(c, event_ms(c.h_only, args.also_steps), ms, ach)
+                if op in ("solve", "gain", "gain_rows"):
+                    rec["roofline"] = _solver_roofline(c, op, ms, rec["roofline"])
                 if c.info is not None:
                     rec["singular_instances"] = int((c.info != 0).sum().item())
                 also.append(rec)
@@ -469,6 +473,31 @@ ALSO = (("msd", "qp", 0, 0, 0), ("quadrotor", "qp", 0, 0, 0), ("long", "qp", 0, 
         ("quadrotor", "loop", 0, 0, 0), ("quadrotor", "gain", 0, 0, 0), ("long", "gain", 0, 0, 0),
         ("two_mass", "gain_rows", 0, 0, 0), ("quadrotor", "gain_rows", 0, 0, 0), ("long", "gain_rows", 0, 0, 0))
 ALSO_BUDGET_S = 120.0  # the extras take about 25 s; beyond this something has regressed and the run fails
+
+def _solver_roofline(case, op, ms, hbm_roofline):
+    """gain / gain_rows / solve on the blocked solver (more than 64 unknowns): the tighter of the two limits.  Algorithmic
+    flops per instance: an LU of the N x N Hessian (2/3 N^3), forward and backward substitution of the right-hand sides
+    (2 N^2 each) and, for the gain, forming Gamma^T blockdiag(Q) (2 N (f r) r) -- the blocked elimination executes more
+    (it eliminates above the pivot block as well: N^3 for the factorisation), which is not counted.  All of it runs on
+    v_mfma_f64_16x16x4_f64.  When the flops at the FP64 matrix peak take longer than the operands at the HBM peak the
+    record is the matrix-core one and keeps the HBM fraction beside it."""
+    N, fr = case.v * case.m, case.f * case.r
+    nrhs = {"gain": fr, "gain_rows": case.m, "solve": 1}[op]
+    fl = 2.0 / 3.0 * N ** 3 + 2.0 * N * N * nrhs
+    if op == "gain":
+        fl += 2.0 * N * fr * case.r
+    elif op == "gain_rows":
+        fl += 2.0 * case.m * N * fr + 2.0 * case.m * fr * case.r
+    t_mfma = fl * case.per_gpu / FP64_PEAK
+    t_hbm = case.unit_bytes * case.per_gpu / HBM_PEAK
+    if N <= 64 or t_mfma <= t_hbm:
+        return hbm_roofline
+    ach = fl * case.per_gpu / (ms * 1e-3)
+    return {"bound": "mfma", "achieved": ach / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP64_PEAK,
+            "traffic": hbm_roofline.get("traffic"), "flops_per_unit": fl, "bytes_per_unit": case.unit_bytes,
+            "hbm_frac": hbm_roofline["frac"], "kernel_ms": ms,
+            "note": "algorithmic flops (LU + substitutions) at the FP64 matrix peak take longer than the operands at the HBM peak"}
+
 
 def _mfma_roofline(case, mfma_ms, step_ms, achieved_bytes_per_s):
     """The contraction kernel against the FP64 matrix-core peak.  `frac` counts the flops the kernel EXECUTES: one

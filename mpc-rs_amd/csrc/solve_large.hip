@@ -13,7 +13,8 @@
 //      below (block Gauss-Jordan) means there is no backward sweep over the matrix.
 //   2. a block of 16 other columns (of H, or of right-hand sides) follows the panel: the panel's row exchanges,
 //      U12 = L11^-1 T for the 16 pivot rows (the inverse of the panel's unit lower triangle is formed once per panel),
-//      and (multipliers) x U12 subtracted from every other 16-row tile on the matrix cores.  Products are computed
+//      and (multipliers) x U12 subtracted from every other 16-row tile on the matrix cores -- evaluated as
+//      (multipliers x L11^-1) x T, the first product taken once per panel when it is factored.  Products are computed
 //      transposed, so that a lane's four accumulators are four columns of one row.
 // What remains is block diagonal with the 16x16 upper triangles U11 of the panels; x_p = U11_p^-1 y_p finishes.
 //
@@ -29,10 +30,9 @@
 // caller's arrays as it is loaded (Gamma^T blockdiag(Q) included), so a right-hand side is read once and its solution
 // written once, and never enters the workspace; the workgroups of one instance run on one XCD and read the same
 // multipliers at about the same time (L2 hits).
-// While panels are applied the block lives in the wavefronts' accumulator registers (lu_applyr_kernel; only the rows a
-// panel's exchanges touch pass through LDS).  lu_apply_kernel, which keeps the block in LDS and moves every tile
-// through it at every step, is the older form of the same kernel: built with -DMPCX_APPLY_LDS for comparison (same
-// results bit for bit; 3-5 % slower on 208- and 800-row systems).
+// While panels are applied the block lives in the wavefronts' accumulator registers (only the rows a panel's exchanges
+// touch pass through LDS), and the stored multipliers are L L11^-1, so that a panel is applied as
+// rows -= (L L11^-1) T straight from the old content T of the pivot rows: one barrier per panel step.
 #include <type_traits>
 #include <utility>
 
@@ -58,11 +58,11 @@ constexpr int kSmallRows = 256;           // the most rows lu_block_kernel (righ
 #ifndef MPCX_LEFT_FROM
 #define MPCX_LEFT_FROM 160
 #endif
-// Systems of more (padded) rows than this are factored left-looking by lu_apply_kernel<..., true>: measured on 16 384
+// Systems of more (padded) rows than this are factored left-looking by lu_applyr_kernel<..., true>: measured on 16 384
 // instances, solve only, right- against left-looking: 128 rows 7.4 / 7.7 ms, 160 rows 11.8 / 11.9 ms, 208 rows 22.4 / 18.1 ms,
 // 240 rows 32.2 / 23.0 ms (the right-looking sweeps move the trailing matrix through memory once per panel).
 constexpr int kLeftFrom = MPCX_LEFT_FROM;
-constexpr int kRhsMaxRows = 8 * 10 * kNB; // the widest variant of lu_apply_kernel: 8 wavefronts x 10 row tiles
+constexpr int kRhsMaxRows = 8 * 10 * kNB; // the widest variant of lu_applyr_kernel: 8 wavefronts x 10 row tiles
 constexpr int kMaxTouched = 2 * kNB;
 
 struct LuArgs {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void lu_pack_transposed_kernel(PackArgs p) {
 // what it leaves behind: the block itself back in the workspace (gcol), L11^-1, U11^-1 and the exchange lists in the
 // panel's description (mt).  RPT: rows a thread holds (RPT THREADS >= nrp).  Returns false on a zero or non-finite
 // pivot.  Kept out of line: inlined into
-// lu_apply_kernel its registers pushed the multipliers of the panel sweep into scratch memory, whose reloads then
+// lu_applyr_kernel its registers pushed the multipliers of the panel sweep into scratch memory, whose reloads then
 // waited behind the prefetched loads of the next panel.
 template <int THREADS, int RPT>
 __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, double *linv, double *uinv, int *tmeta,
@@ -338,6 +338,33 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
         if (lane < kNB) tmeta[kEntAt + lane] = kNB + lane < nt ? ((osrc - k0) | (lane << 8)) : -1;  // outside row `lane`: the pivot-block row it receives, its place in the list
     }
     __syncthreads();
+    // The multipliers as the later blocks use them.  A row outside the pivot block is reduced by (its multipliers) x U12
+    // with U12 = L11^-1 T, T the old content of the pivot rows: the product with L11^-1 is taken here, once per panel, so
+    // that a block applies the panel as rows -= (L L11^-1) T with no U12 to wait for.  The pivot block's own place takes
+    // -L11^-1: its new rows L11^-1 T are the same product started from zero (U11 lives on in U11^-1 only).
+    {
+        const int kq = lane >> 4, l15 = lane & 15;
+        double la[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) la[q] = linv[(kq + 4 * q) * kNB + l15];  // first operand [c = lane & 15][k] = L11^-1[k][c]
+        for (int t = wv; t < nrp / kNB; t += NW) {
+            const int r0 = t * kNB;
+            if (r0 == k0) {  // uniform over the wavefront
+#pragma unroll
+                for (int q = 0; q < 4; ++q) blk[(kq + 4 * q) * ld + k0 + l15] = -linv[l15 * kNB + kq + 4 * q];
+            } else {
+                double lm[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lm[q] = blk[(kq + 4 * q) * ld + r0 + l15];  // second operand [k][row lane & 15] = L[row][k]
+                d4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], lm[q], d, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) blk[(kq + 4 * q) * ld + r0 + l15] = d[q];  // [c = kq + 4 q][row lane & 15]
+            }
+        }
+    }
+    __syncthreads();
     FSTAMP(18);
     // the block goes back to the workspace (one contiguous run), 16-byte pieces, every LDS read of a round issued first
     {
@@ -365,7 +392,7 @@ __device__ __noinline__ bool factor_block(double *blk, int ld, int nrp, int k0, 
 
 // Right-looking, for systems of up to kSmallRows rows (used up to kLeftFrom): their time goes into the barriers of the
 // panel factorization, and a workgroup of 256 threads within 128 registers lets four instances share a CU.  (Larger
-// systems are factored left-looking by lu_apply_kernel<..., true>, which moves half the bytes.)
+// systems are factored left-looking by lu_applyr_kernel<..., true>, which moves half the bytes.)
 constexpr int kThreads = 256, kWaves = kThreads / 64;
 __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
     extern __shared__ __align__(16) double sm[];
@@ -445,16 +472,17 @@ __global__ __launch_bounds__(kThreads, 4) void lu_block_kernel(LuArgs p) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // U12 = L11^-1 T: D[row (lane >> 4) + 4 q][col lane & 15]
-            d4 u12 = {0.0, 0.0, 0.0, 0.0};
+            d4 u12 = {0.0, 0.0, 0.0, 0.0}, nu;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double tb = mytile[((lane >> 4) + 4 * q) * kNB + (lane & 15)];
+                nu[q] = -tb;
                 u12 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], tb, u12, 0, 0, 0);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) A[(size_t)(c0 + (lane & 15)) * nrp + k0 + (lane >> 4) + 4 * q] = u12[q];
-            // every other 16-row tile: C^T -= U12^T L^T.  A operand [i' = column][k] = U12[k][column] is u12 as it stands.
-            const d4 nu = -u12;
+            // every other 16-row tile: C^T -= T^T (L L11^-1)^T.  A operand [i' = column][k] = T[k][column].
+            // (the stored multipliers are L L11^-1: the tiles are reduced by (L L11^-1) T, nu = -T)
             const int pidx = k0 / kNB, nt = nrp / kNB - 1;
             double *cbase = A + (size_t)(c0 + (lane >> 4)) * nrp + (lane & 15);  // + r0, + 4 q columns
             auto row0 = [&](int t) { return (t < pidx ? t : t + 1) * kNB; };
@@ -503,15 +531,13 @@ struct RhsArgs {
     long long first, count, W, total;  // total = count x blocks per instance
     int nr, nrhs, r, nrp, negate, ld;
 };
-#ifndef MPCX_RHS_ABLATE
-#define MPCX_RHS_ABLATE 0  // experiments only (wrong results): 1 no block load, 2 no panels, 4 no tile updates, 8 no U11 step, 16 no write, 64 every multiplier request to the same tile
-#endif
 constexpr int kMaxWeightBlock = 64;  // widest output weight block r served
 
 // Leading dimension of the LDS block: the four column groups of a tile access (lane >> 4) land 16 doubles apart
 // modulo 32, so that the two groups served together use disjoint banks.
 int rhs_ld(int nrp) { return (nrp % 32 == 0) ? nrp + 16 : nrp; }
 
+// ---- a block of 16 columns follows the panels: right-hand sides, and H's own column blocks (left-looking) ----
 // THREADS: workgroup size (>= 256); MT: row tiles per wavefront (THREADS / 64 * MT * 16 >= nrp).
 //
 // FACTOR: the same machinery run over H's own column blocks, left-looking, one workgroup per instance: block j is
@@ -519,428 +545,22 @@ int rhs_ld(int nrp) { return (nrp % 32 == 0) ? nrp + 16 : nrp; }
 // panel j (pivot search, exchanges, multipliers for every row outside the pivot block) and written back with what the
 // later blocks need.  H's columns are read and written once; what is streamed per block are the multipliers of the
 // panels before it, half the bytes of a right-looking sweep over the trailing columns and reads only.
-template <int THREADS, int MT, bool FACTOR>
-__global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : 4) : 1) void lu_apply_kernel(RhsArgs p) {  // at most 16 wavefronts (LDS slots)
-    extern __shared__ __align__(16) double sm[];
-    constexpr int NW = THREADS / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wvs = __builtin_amdgcn_readfirstlane(wv);  // the same number in a scalar register: conditions on it are branches, not masks
-    // Row tiles are dealt to the wavefronts round-robin, starting at a wavefront that differs from workgroup to workgroup:
-    // the tiles seldom divide evenly (13 over 4 wavefronts), wavefront i of every workgroup sits on SIMD i, and the step is
-    // bound by the matrix pipe of the busiest SIMD -- without the rotation that is always the same one.
-#ifndef MPCX_NO_TILE_ROTATION
-    const int wr = (wvs + (int)(blockIdx.x >> 3)) & (NW - 1);
-#else
-    const int wr = wvs;
-#endif
-    const int nrp = p.nrp, ld = p.ld, npan = nrp / kNB, nblk = (p.nrhs + kNB - 1) / kNB;
-    // Workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (instance, block) pairs, so
-    // that the blocks of one instance, which read the same multipliers, share one L2.
-    const long long per_xcd = (p.total + 7) / 8;
-    const long long item = FACTOR ? (long long)blockIdx.x : (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (!FACTOR && ((blockIdx.x >> 3) >= per_xcd || item >= p.total)) return;
-    const long long li = FACTOR ? item : item / nblk;
-    const int bk = FACTOR ? 0 : (int)(item - li * nblk), c0 = bk * kNB;
-    const long long b = p.first + li;
-    double *A = p.ws + (size_t)li * nrp * nrp;
-    double *blk = sm;                       // [16][ld]: blk[c * ld + row]
-    double *u12s = blk + (size_t)kNB * ld;  // [16][16]: u12s[row * 16 + col]
-    double *linv = u12s + kNB * kNB;        // [16][16]
-    int *tmeta = (int *)(linv + kNB * kNB); // tcount, trow[32], tsrc[32]
-#ifdef MPCX_RHS_STAMPS
-    const long long rs_t0 = wall_clock64();
-    long long rs_t1 = 0, rs_t2 = 0;
-#endif
-    const bool bad = !FACTOR && p.failed[li] != 0;
-    if (!FACTOR && p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
-    const long long ER = (long long)p.nr * p.nrhs;
-    if (bad) {  // uniform over the workgroup
-        for (int e = tid; e < kNB * p.nr; e += THREADS) {
-            const int c = e / p.nr, row = e - c * p.nr;
-            if (c0 + c < p.nrhs) p.X[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] = __longlong_as_double(0x7ff8000000000000LL);
-        }
-        return;
-    }
-    const int kq = lane >> 4, l15 = lane & 15;
-    const int lofs = kq * nrp + l15;  // a lane's place in a tile of multipliers: + panel's first column, + 4 q columns, + r0
-    double *meta = p.meta + (size_t)li * npan * kMetaDoubles;
-    double lb[MT][4];
-    // The multipliers of a wavefront's tiles live in ONE set of registers: right after a tile's products have used them,
-    // the same registers are requested for the next panel, so the requests trickle into the memory pipeline between the
-    // products of a whole step instead of queueing up in front of it (36 requests in a row kept a wavefront 1-2 us at the
-    // queue's door), and each has a whole step to arrive.  Every load is issued unconditionally (a tile slot past the last
-    // tile, or the panel's own tile, reads the last tile / itself and the value is dropped): with a fixed number of loads
-    // per step the compiler can wait for "all but the loads issued since" when a multiplier is first used; behind a
-    // condition it cannot, and waits for every outstanding load.
-    auto fetch_one = [&](int pn, int u, int q) __attribute__((always_inline)) {
-        const int t0 = wr + NW * u, t = t0 < npan ? t0 : npan - 1;
-        if (MPCX_RHS_ABLATE & 64) return A[(unsigned)(lofs + 4 * q * nrp)];  // (every request hits the same 2 KB)
-        return A[(unsigned)(lofs + (pn * kNB + 4 * q) * nrp + t * kNB)];
-    };
-    auto fetch_tile = [&](int pn, int u, double(&dst)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = fetch_one(pn, u, q);
-    };
-    // A panel's description is fetched one panel ahead: L11^-1 one entry per thread (it reaches the first wavefront
-    // through LDS), and in the first wavefront the rows the 16 pivot rows come from, in the layout its
-    // matrix-core product wants ([k = (lane >> 4) + 4 q]), and of the displaced rows the one this lane moves (entry
-    // 16 + (lane & 15) of the lists).
-    double m_linv = 0.0;
-    int m_ts[4] = {0, 0, 0, 0}, m_mvs = 0, m_mvd = 0, m_nt = 0;
-    auto fetch_meta = [&](int pn) {
-        const double *mt = meta + (size_t)pn * kMetaDoubles;
-        if (tid < kNB * kNB) m_linv = mt[tid];
-        if (wv != 0) return;
-        const int *mi = (const int *)(mt + kMetaInts);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) m_ts[q] = mi[1 + kMaxTouched + kq + 4 * q];
-        m_nt = mi[0];
-        m_mvd = mi[1 + kNB + l15];
-        m_mvs = mi[1 + kMaxTouched + kNB + l15];
-    };
-    // The block: 16 columns of the right-hand side, rows beyond nr and columns beyond nrhs zero.
-    if (FACTOR || (MPCX_RHS_ABLATE & 1)) {
-    } else if (p.Q == nullptr) {
-        for (int e = tid; e < kNB * nrp; e += THREADS) {
-            const int c = e / nrp, row = e - c * nrp;
-            blk[c * ld + row] = (row < p.nr && c0 + c < p.nrhs) ? p.R[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] : 0.0;
-        }
-    } else {
-        // Gamma^T blockdiag(Q) (controller.rs:96, M^T W4): column c = g r + a2, row k is sum_a Gamma[g r + a][k] Q[a2][a]
-        // (Q stored column-major: Q[a2 * r + a]).  The block's 16 columns touch the rows [lo, hi) of Gamma, a contiguous
-        // run per unknown k of the column-major (f r) x (v m) array.  Per tile of 16 unknowns the block is the product
-        // D[column][unknown] = sum_j S[column][j] Gamma[lo + j][unknown], S the selection of Q's entries (zero where row
-        // lo + j lies outside the column's weight block): on the matrix cores, Gamma read straight from memory.
-        const int r = p.r, lo = (c0 / r) * r;
-        int hi = ((c0 + kNB - 1) / r + 1) * r;
-        if (hi > p.nrhs) hi = p.nrhs;
-        const int w = hi - lo, ns = (w + 3) / 4;
-        const bool q_lds = r * r <= kNB * kNB;  // the weight block rides in LDS (the U12 buffer is idle until the panels start)
-        if (q_lds) {
-            for (int e = tid; e < r * r; e += THREADS) u12s[e] = p.Q[e];
-            __syncthreads();
-        }
-        const double *qw = q_lds ? u12s : p.Q;
-        const int cc = c0 + l15, g = cc / r, a2 = cc - g * r, joff = lo - g * r;  // A operand: column lane & 15
-        if (ns <= 6) {
-            // (the usual case: the 16 columns touch at most 24 rows of Gamma)  Four tiles of a wavefront at a time, every
-            // load of the four issued before the first product: one memory latency per four tiles.
-            constexpr int TB = 4, NS = 6;
-            double qa[NS];
-#pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                const int jj = 4 * u + kq, ja = jj + joff;
-                qa[u] = (cc < p.nrhs && jj < w && ja >= 0 && ja < r) ? qw[a2 * r + ja] : 0.0;
-            }
-            for (int tb0 = wv; tb0 < npan; tb0 += NW * TB) {
-                double gb[TB][NS];
-#pragma unroll
-                for (int i = 0; i < TB; ++i) {
-                    const int t = tb0 + i * NW, k = t * kNB + l15;  // B operand: unknown lane & 15
-#pragma unroll
-                    for (int u = 0; u < NS; ++u) {
-                        const int jj = 4 * u + kq;
-                        gb[i][u] = (t < npan && k < p.nr && jj < w) ? p.R[elem_index(b, (long long)k * p.nrhs + lo + jj, ER, p.W)] : 0.0;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < TB; ++i) {
-                    const int t = tb0 + i * NW;
-                    d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int u = 0; u < NS; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[u], gb[i][u], acc, 0, 0, 0);  // (zeros past w)
-                    if (t < npan) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) blk[(kq + 4 * q) * ld + t * kNB + l15] = acc[q];
-                    }
-                }
-            }
-        } else {
-        constexpr int SC = 12;  // steps of four rows of Gamma in flight per tile
-        for (int t = wv; t < npan; t += NW) {
-            const int k = t * kNB + l15;  // B operand: unknown lane & 15
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            for (int s0 = 0; s0 < ns; s0 += SC) {
-                double gb[SC], qa[SC];
-#pragma unroll
-                for (int u = 0; u < SC; ++u) {
-                    const int jj = 4 * (s0 + u) + kq, ja = jj + joff;
-                    gb[u] = (k < p.nr && jj < w) ? p.R[elem_index(b, (long long)k * p.nrhs + lo + jj, ER, p.W)] : 0.0;
-                    qa[u] = (cc < p.nrhs && jj < w && ja >= 0 && ja < r) ? qw[a2 * r + ja] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < SC; ++u)
-                    if (s0 + u < ns) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[u], gb[u], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) blk[(kq + 4 * q) * ld + t * kNB + l15] = acc[q];
-        }
-        }
-        __syncthreads();  // the weight block leaves the U12 buffer
-    }
-    // Diagnostic build (-DMPCX_RHS_STAMPS, tools/probe_rhs.py): lane 0 of every wavefront adds up, over the panels, the time
-    // it spends waiting at the step's first barrier, in the first wavefront's section and the requests, at the second
-    // barrier and in the tile updates; block 0 of every instance leaves the sums at the start of its instance's X.
-#ifdef MPCX_RHS_STAMPS
-    long long rs_last = 0;
-    double rs_sum[4] = {0.0, 0.0, 0.0, 0.0};
-#define RSTAMP(k) do { const long long now_ = wall_clock64(); if ((k) > 0) rs_sum[(k) - 1] += (double)(now_ - rs_last); rs_last = now_; } while (0)
-#else
-#define RSTAMP(k) do {} while (0)
-#endif
-    d4 acc_keep[MT] = {};
-    auto panel_step = [&](int pn, int upto) __attribute__((always_inline)) {
-        if ((MPCX_RHS_ABLATE & 2) && pn >= 0) return;
-        // (The barriers of a step order LDS traffic only: a __syncthreads() would also wait for the multipliers that were
-        // just requested for the next panel.)
-        const int k0 = pn * kNB;
-        RSTAMP(0);
-        if (tid < kNB * kNB) linv[tid] = m_linv;
-        lds_barrier();  // the previous panel's updates (and the initial load) are in place
-        RSTAMP(1);
-        // The first wavefront alone: the 16 pivot rows, read where they lie before the panel's exchanges, give
-        // U12 = L11^-1 T as one 16x16x16 product; the displaced rows are carried over.  Every read precedes every write
-        // within the wavefront (LDS operations of a wavefront execute in order), so the exchange needs no barrier.
-        // The requests for the next panel go out after it: nothing on this path waits for a load it has just issued.
-        if (wv == 0 && !(MPCX_RHS_ABLATE & 32)) {
-            double la[4], tb[4], mv[4];
-            const int mvs = m_mvs, mvd = m_mvd;
-            const bool moves = kNB + l15 < m_nt;
-            // (lane indices the compiler cannot see through: the addresses below are formed here, in a few instructions,
-            // instead of being kept in twenty registers across the whole panel loop)
-            int li = l15, ki = kq;
-            asm volatile("" : "+v"(li), "+v"(ki));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                la[q] = linv[li * kNB + ki + 4 * q];           // A operand: L11^-1[i = l15][k = kq + 4 q]
-                tb[q] = blk[li * ld + m_ts[q]];                // B operand: T[k = kq + 4 q][column l15]
-            }
-            d4 u12 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) u12 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], tb[q], u12, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) mv[q] = blk[(ki + 4 * q) * ld + (moves ? mvs : 0)];  // row mvs, column kq + 4 q
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {  // D[i = kq + 4 q][column l15]
-                blk[li * ld + k0 + ki + 4 * q] = u12[q];
-                u12s[(ki + 4 * q) * kNB + li] = u12[q];
-                if (moves) blk[(ki + 4 * q) * ld + mvd] = mv[q];
-            }
-        }
-        const int pf = pn + 1 < upto ? pn + 1 : pn;  // the panel to request (after the last one: itself again, unused)
-        fetch_meta(pf);
-        RSTAMP(2);
-        lds_barrier();
-        RSTAMP(3);
-        d4 nu;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) nu[q] = -u12s[(kq + 4 * q) * kNB + l15];
-        const int cofs = kq * ld + l15;  // + 4 q columns, + r0
-        // The same loads for every tile slot: a slot past the last tile, or the panel's own tile, requests the last tile's /
-        // its own multipliers and drops them, so that the number of loads in flight does not depend on the path taken; its
-        // products and its write-back are skipped (a branch: the condition is uniform over the wavefront).  Every tile of
-        // the wavefront is read before the first product (one LDS round trip per step, not one per tile).
-        d4 (&acc)[MT] = acc_keep;
-        if (!(MPCX_RHS_ABLATE & 128)) {  // (128: the tiles stay in registers from step to step, no LDS traffic for them)
-#pragma unroll
-        for (int u = 0; u < MT; ++u) {
-            const int t0 = wr + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[u][q] = blk[cofs + 4 * q * ld + r0];
-        }
-        }
-#ifdef MPCX_TILE_AFTER_TILE
-#pragma unroll
-        for (int u = 0; u < MT; ++u) {
-            const int t0 = wr + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
-            const bool live = t0 < npan && t0 != pn && !(MPCX_RHS_ABLATE & 4);  // uniform over the wavefront
-            if (live) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb[u][q], acc[u], 0, 0, 0);
-            }
-            fetch_tile(pf, u, lb[u]);
-            if (live && !(MPCX_RHS_ABLATE & 128)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) blk[cofs + 4 * q * ld + r0] = acc[u][q];
-            }
-        }
-#else
-        // A tile's four products form a dependent chain (each waits for the one before: about twice the issue interval), so
-        // the products go quarter by quarter of the contraction, the wavefront's tiles side by side; each multiplier is
-        // requested again, for the next panel, right behind the product that used it.  The order is pinned: left to itself
-        // the scheduler gathers the requests into bursts and the waits stop counting.
-        bool live[MT];
-#pragma unroll
-        for (int u = 0; u < MT; ++u) {
-            const int t0 = wr + NW * u;
-            live[u] = t0 < npan && t0 != pn && !(MPCX_RHS_ABLATE & 4);  // uniform over the wavefront
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int u = 0; u < MT; ++u) {
-                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb[u][q], acc[u], 0, 0, 0);
-                lb[u][q] = fetch_one(pf, u, q);
-                __builtin_amdgcn_sched_barrier(7);  // (scalar and vector arithmetic may cross, matrix and memory instructions may not)
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < MT; ++u) {
-            const int t0 = wr + NW * u, r0 = (t0 < npan ? t0 : npan - 1) * kNB;
-            if (live[u]) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) blk[cofs + 4 * q * ld + r0] = acc[u][q];
-            }
-        }
-#endif
-        RSTAMP(4);
-    };
-    // the panels [0, upto) applied to the block in LDS
-    auto apply_panels = [&](int upto) __attribute__((always_inline)) {
-        if (upto <= 0) return;
-        fetch_meta(0);
-#ifdef MPCX_TILE_AFTER_TILE
-#pragma unroll
-        for (int u = 0; u < MT; ++u) fetch_tile(0, u, lb[u]);
-#else
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {  // (in the order the steps re-request them)
-#pragma unroll
-            for (int u = 0; u < MT; ++u) {
-                lb[u][q] = fetch_one(0, u, q);
-                __builtin_amdgcn_sched_barrier(7);
-            }
-        }
-#endif
-        for (int pn = 0; pn < upto; ++pn) panel_step(pn, upto);
-    };
-    if constexpr (FACTOR) {
-        double *red_val = (double *)(tmeta + kTmetaInts);  // [NW]
-        int *red_idx = (int *)(red_val + NW);                       // [NW]
-        int *ipiv = red_idx + NW;                                   // [16]
-        double *uinv = u12s;
-        for (int j = 0; j < npan; ++j) {
-#ifdef MPCX_LU_STAMPS
-            double *stamps = p.X + (size_t)li * p.nr * p.nrhs + 4 * j;
-            if (tid == 0) stamps[0] = (double)wall_clock64();
-#endif
-            const int k0 = j * kNB;
-            double *gcol = A + (size_t)k0 * nrp;  // the block's 16 columns are one contiguous run of the workspace
-            {   // the block, 16-byte pieces, eight loads in flight per thread
-                typedef double v2d __attribute__((ext_vector_type(2)));
-                const int pairs = kNB * nrp / 2;
-                for (int e0 = tid; e0 < pairs; e0 += 8 * THREADS) {
-                    v2d v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int e = e0 + u * THREADS;
-                        v[u] = *(const v2d *)(gcol + 2 * (e < pairs ? e : 0));
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int e = e0 + u * THREADS;
-                        if (e < pairs) {
-                            const int c = (2 * e) / nrp, row2 = 2 * e - c * nrp;
-                            *(v2d *)(blk + c * ld + row2) = v[u];
-                        }
-                    }
-                }
-            }
-#ifdef MPCX_LU_STAMPS
-            __syncthreads();
-            if (tid == 0) stamps[1] = (double)wall_clock64();
-#endif
-            apply_panels(j);
-            __syncthreads();
-#ifdef MPCX_LU_STAMPS
-            if (tid == 0) stamps[2] = (double)wall_clock64();
-#endif
-            // (rows a thread holds: the variant serves at most NW MT tiles of 16 rows)
-            if (!factor_block<THREADS, (NW * MT * kNB + THREADS - 1) / THREADS>(blk, ld, nrp, k0, linv, uinv, tmeta, red_val, red_idx, ipiv, gcol,
-                                       meta + (size_t)j * kMetaDoubles
-#ifdef MPCX_LU_STAMPS
-                                       , p.X + (size_t)li * p.nr * p.nrhs + 4 * npan + 20 * j
-#endif
-                                       )) {
-                if (tid == 0) p.failed[li] = 1;
-                return;
-            }
-            // The next blocks stream this panel back, and only this workgroup does: the barrier (a workgroup-scope
-            // release / acquire over global memory as well) is all the ordering that takes.  A device-scope fence here
-            // would write the whole L2's dirty lines back to memory once per block.
-            __syncthreads();
-#ifdef MPCX_LU_STAMPS
-            if (tid == 0) stamps[3] = (double)wall_clock64();
-#endif
-        }
-        return;
-    }
-#ifdef MPCX_RHS_STAMPS
-    rs_t1 = wall_clock64();
-#endif
-    apply_panels(npan);
-#ifdef MPCX_RHS_STAMPS
-    rs_t2 = wall_clock64();
-#endif
-    // x_p = U11_p^-1 y_p per panel, in place: one 16x16x16 product per panel, panels dealt to the wavefronts.  Every
-    // inverse of the wavefront's panels is requested before the first product (the multipliers' registers are free now).
-    double un[MT][4];
-#pragma unroll
-    for (int u = 0; u < MT; ++u) {
-        const int pn0 = wvs + NW * u, pn = pn0 < npan ? pn0 : npan - 1;
-        const double *ui = meta + (size_t)pn * kMetaDoubles + kNB * kNB;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) un[u][q] = ui[l15 * kNB + kq + 4 * q];  // A operand: U11^-1[i = lane & 15][k]
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < MT; ++u) {
-        const int pn = wvs + NW * u;
-        if (pn < npan && !(MPCX_RHS_ABLATE & 8)) {
-            double yb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) yb[q] = blk[l15 * ld + pn * kNB + kq + 4 * q];  // B operand: y[k][column lane & 15]
-            d4 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(un[u][q], yb[q], x, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) blk[l15 * ld + pn * kNB + kq + 4 * q] = x[q];  // D[i = (lane >> 4) + 4 q][column lane & 15]
-        }
-    }
-    __syncthreads();
-    const double sign = p.negate ? -1.0 : 1.0;
-    for (int e = tid; e < kNB * p.nr && !(MPCX_RHS_ABLATE & 16); e += THREADS) {
-        const int c = e / p.nr, row = e - c * p.nr;
-        if (c0 + c < p.nrhs) p.X[elem_index(b, (long long)(c0 + c) * p.nr + row, ER, p.W)] = sign * blk[(size_t)c * ld + row];
-    }
-#ifdef MPCX_RHS_STAMPS
-    __syncthreads();  // (orders this workgroup's result stores before the stamps that overwrite some of them)
-    if (bk == 1 && lane == 0) {  // block 1: a block in the middle of the launch's work, written last of its instance's first columns
-        double *o = p.X + (size_t)b * p.nr * p.nrhs + wv * 8;
-        for (int k = 0; k < 4; ++k) o[k] = rs_sum[k];
-        const long long t3 = wall_clock64();
-        o[4] = (double)(rs_t1 - rs_t0);
-        o[5] = (double)(rs_t2 - rs_t1);
-        o[6] = (double)(t3 - rs_t2);
-    }
-#endif
-}
-
-
-// ---- the same with the block in registers ----
+//
 // A block of 16 columns is 2 KB per 16-row tile: a wavefront keeps its tiles in its accumulator registers (lane
 // (kq, l15) holds columns kq + 4 q of row l15, the layout the products leave them in) through all the panels, and only
 // the rows a panel's exchanges touch travel through LDS -- the 16 rows of the pivot block and the rows outside it that
-// trade places with them, 32 at most -- instead of every tile being read from and written back to LDS at every step
-// (with the tiles in LDS the steps were bound by LDS bandwidth: 2 x 103 KB per step and workgroup at 800 rows).
+// trade places with them, 32 at most.  (With the tiles in LDS, read and written back at every step, the steps were
+// bound by LDS bandwidth: 2 x 103 KB per step and workgroup at 800 rows.)
 //
-// Per step: (A) the owner of the pivot block's tile and the owners of touched outside rows put those rows' old content
+// Per step: the owner of the pivot block's tile and the owners of touched outside rows put those rows' old content
 // into the list old[0..15] / old[16..]; a table row -> (pivot-block row it receives, place in the list) tells a lane
-// whether its row is touched, the first wavefront keeps it current one panel ahead; (barrier) the first wavefront forms
-// U12 = L11^-1 T from the list (the panel's description says where in the list each pivot row's source lies);
-// (barrier) the pivot block's tile becomes U12, a touched outside row takes the old content of the pivot-block row the
-// table names, every other tile gets its rank-16 update.  The list is double-buffered by the step's parity: a fast
-// wavefront may already publish rows of the next step while a slow one still reads this step's.
+// whether its row is touched, the first wavefront keeps it current one panel ahead.  After ONE barrier every wavefront
+// reads T -- the old content of the pivot rows, found in the list through the panel's description -- as the first
+// operand of its products: a touched outside row first takes the old content of the pivot-block row the table names,
+// then every tile is reduced by (its stored multipliers) x T.  The stored multipliers are L L11^-1 (factor_block), so
+// there is no U12 = L11^-1 T to wait for; the pivot block's tile, whose place in the workspace holds -L11^-1, starts
+// from zero and becomes U12 by the same product.  The list is double-buffered by the step's parity: a fast wavefront
+// may already publish rows of the next step while a slow one still reads this step's.
 constexpr int kTS = kNB + 1;  // row stride of a 16 x 16 tile staged in LDS (an odd stride: rows and columns both spread over the banks)
 
 #ifndef MPCX_RHS_WGS
@@ -961,18 +581,17 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : MPCX_RHS_WG
     const int bk = FACTOR ? 0 : (int)(item - li * nblk), c0 = bk * kNB;
     const long long b = p.first + li;
     double *A = p.ws + (size_t)li * nrp * nrp;
-    // LDS: L11^-1; with FACTOR what the panel factorisation needs beside its block; then the step's buffers -- which the
-    // block being factored overlays (it is in registers while the panels are applied and in LDS while it is factored).
-    double *linv = sm;                                           // [16][16]
+    // LDS: with FACTOR what the panel factorisation needs beside its block; then the step's buffers -- which the block
+    // being factored overlays (it is in registers while the panels are applied and in LDS while it is factored).
+    double *linv = sm;                                           // FACTOR: [16][16]
     double *uinv = linv + kNB * kNB;                             // FACTOR: [16][16]
     int *tmeta = (int *)(uinv + kNB * kNB);                      // FACTOR: a panel's exchange lists as factor_block leaves them
     double *red_val = (double *)(tmeta + kTmetaInts);            // FACTOR: [NW]
     int *red_idx = (int *)(red_val + NW);                        // FACTOR: [NW]
     int *ipiv = red_idx + NW;                                    // FACTOR: [16]
-    double *old = FACTOR ? (double *)(ipiv + kNB) : linv + kNB * kNB;  // [2][32][kTS]
+    double *old = FACTOR ? (double *)(ipiv + kNB) : sm;          // [2][32][kTS]
     double *blk = old;                                           // FACTOR: [16][ld], over the step's buffers
-    double *u12s = old + 2 * kMaxTouched * kTS;                  // [16][kTS]: U12[row][column]
-    double *xp = u12s + kNB * kTS;                               // right-hand sides: [NW][16][kTS], a wavefront's own tile for transposing
+    double *xp = old + 2 * kMaxTouched * kTS;                    // right-hand sides: [NW][16][kTS], a wavefront's own tile for transposing; the weight block while the block is formed
     int *table = (int *)(xp + (FACTOR ? 0 : NW * kNB * kTS));    // [2][nrp], by the panel's parity
     const bool bad = !FACTOR && p.failed[li] != 0;
     if (!FACTOR && p.info && bk == 0 && tid == 0) p.info[b] = bad ? 1 : 0;
@@ -1014,20 +633,18 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : MPCX_RHS_WG
         l_ent = mi[kEntAt + l15];
         l_row = mi[1 + kNB + l15];
     };
-    double m_linv = 0.0;
-    auto fetch_linv = [&](int pn) __attribute__((always_inline)) {  // (every thread, the upper half of a larger workgroup for nothing: no request behind a condition)
-        m_linv = meta[(size_t)pn * kMetaDoubles + (tid & (kNB * kNB - 1))];
-    };
     auto panel_step = [&](int pn, int upto) __attribute__((always_inline)) {
         double *ob = old + (pn & 1) * (kMaxTouched * kTS);
         int *tab = table + (pn & 1) * nrp, *tab_next = table + ((pn + 1) & 1) * nrp;
-        // (A) which of this wavefront's rows the panel touches (the entry is cleared by the lane that read it: the table
-        // of this parity is clean again when the first wavefront fills it for the panel after the next); their old
-        // content into the list
+        // Which of this wavefront's rows the panel touches (the entry is cleared by the lane that read it: the table of
+        // this parity is clean again when the first wavefront fills it for the panel after the next); their old content
+        // into the list.
         int s[MT];
 #pragma unroll
         for (int u = 0; u < MT; ++u) s[u] = tab[tile0[u] + l15];
-        if (tid < kNB * kNB) linv[tid] = m_linv;
+        // the next panel's touched outside rows into the table of the other parity (lanes 0..15 of the first wavefront,
+        // one row each): every look-up of that table's previous use lies before the previous step's barrier
+        if (wvs == 0 && lane < kNB && pn + 1 < upto && l_ent >= 0) tab_next[l_row] = l_ent;
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             const bool mine = owned[u] && tile0[u] == pn * kNB;  // uniform over the wavefront
@@ -1043,53 +660,37 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : MPCX_RHS_WG
             }
         }
         lds_barrier();
-        if (wvs == 0) {
-            double la[4], tb[4];
-            int li2 = l15, ki = kq;
-            asm volatile("" : "+v"(li2), "+v"(ki));
+        // first operand of every product of the step: [column l15][k = kq + 4 q] = -T[k][column], T[k] the old content of
+        // the row that becomes pivot row k
+        d4 nt;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                la[q] = linv[li2 * kNB + ki + 4 * q];                         // A operand: L11^-1[i = l15][k = kq + 4 q]
-                tb[q] = ob[((at_cur >> (8 * q)) & 255) * kTS + li2];          // B operand: T[k = kq + 4 q][column l15]
-            }
-            d4 u12 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) u12 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[q], tb[q], u12, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) u12s[(ki + 4 * q) * kTS + li2] = u12[q];  // D[i = kq + 4 q][column l15]
-            // the next panel's touched outside rows into the table of the other parity (lanes 0..15, one row each)
-            if (lane < kNB && pn + 1 < upto && l_ent >= 0) tab_next[l_row] = l_ent;
-        }
-        at_cur = l_atp;
-        fetch_lists(pn + 2 < upto ? pn + 2 : upto - 1);
-        const int pf = pn + 1 < upto ? pn + 1 : pn;
-        fetch_linv(pf);
-        lds_barrier();
-        d4 nu;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) nu[q] = -u12s[(kq + 4 * q) * kTS + l15];
-        // touched rows take their new content: the pivot block's tile becomes U12, an outside row the old content of the
-        // pivot-block row the table names (loads under a uniform branch, the choice per lane)
+        for (int q = 0; q < 4; ++q) nt[q] = -ob[((at_cur >> (8 * q)) & 255) * kTS + l15];
+        // touched outside rows take the old content of the pivot-block row the table names (loads under a uniform
+        // branch, the choice per lane); the pivot block's tile starts from zero
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             const bool mine = owned[u] && tile0[u] == pn * kNB;
             const bool any = __builtin_amdgcn_ballot_w64(s[u] >= 0) != 0;
-            if (mine || any) {
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[u][q] = 0.0;
+            } else if (any) {
                 double nv[4];
-                const double *from = mine ? u12s + l15 * kTS : ob + ((s[u] >= 0 ? s[u] : 0) & 255) * kTS;
+                const double *from = ob + ((s[u] >= 0 ? s[u] : 0) & 255) * kTS;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) nv[q] = from[kq + 4 * q];
-                const bool take = mine || s[u] >= 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[u][q] = take ? nv[q] : acc[u][q];
+                for (int q = 0; q < 4; ++q) acc[u][q] = s[u] >= 0 ? nv[q] : acc[u][q];
             }
         }
+        at_cur = l_atp;
+        fetch_lists(pn + 2 < upto ? pn + 2 : upto - 1);
+        const int pf = pn + 1 < upto ? pn + 1 : pn;
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            const bool live = owned[u] && tile0[u] != pn * kNB;  // uniform over the wavefront
-            if (live) {
+            if (owned[u]) {  // uniform over the wavefront
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nu[q], lb[u][q], acc[u], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nt[q], lb[u][q], acc[u], 0, 0, 0);
             }
             fetch_tile(pf, u, lb[u]);
         }
@@ -1105,7 +706,6 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : MPCX_RHS_WG
         if (wvs == 0 && lane < kNB && l_ent >= 0) table[l_row] = l_ent;
         at_cur = l_atp;
         fetch_lists(upto > 1 ? 1 : 0);
-        fetch_linv(0);
         lds_barrier();  // the tables (cleared by everyone, the first panel's entries set) before the first look-up
 #pragma unroll
         for (int u = 0; u < MT; ++u) fetch_tile(0, u, lb[u]);
@@ -1166,12 +766,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : MPCX_RHS_WG
         int hi = ((c0 + kNB - 1) / r + 1) * r;
         if (hi > p.nrhs) hi = p.nrhs;
         const int w = hi - lo, ns = (w + 3) / 4;
-        const bool q_lds = r * r <= kNB * kNB;  // the weight block rides in LDS (the U12 buffer is idle until the panels start)
+        const bool q_lds = r * r <= kNB * kNB;  // the weight block rides in LDS (the wavefronts' transposing tiles are idle until the end)
         if (q_lds) {
-            for (int e = tid; e < r * r; e += THREADS) u12s[e] = p.Q[e];
+            for (int e = tid; e < r * r; e += THREADS) xp[e] = p.Q[e];
             __syncthreads();
         }
-        const double *qw = q_lds ? u12s : p.Q;
+        const double *qw = q_lds ? xp : p.Q;
         const int cc = c0 + l15, g = cc / r, a2 = cc - g * r, joff = lo - g * r;  // A operand: column lane & 15
         if (ns <= 6) {
             // (the usual case: the 16 columns touch at most 24 rows of Gamma)  Four tiles of a wavefront at a time, every
@@ -1224,7 +824,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : MPCX_RHS_WG
                 acc[u] = a;
             }
         }
-        __syncthreads();  // the weight block leaves the U12 buffer
+        __syncthreads();  // the weight block leaves the transposing tiles
     }
     apply_panels(npan);
     // x_p = U11_p^-1 y_p per tile, where it lies: X^T = Y^T U11^-T needs the tile transposed as its first operand -- through
@@ -1259,8 +859,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? (FACTOR ? 3 : MPCX_RHS_WG
 }
 
 size_t applyr_lds_bytes(int nrp, int nw, bool factor) {
-    const size_t step = (2 * kMaxTouched * kTS + kNB * kTS + (factor ? 0 : (size_t)nw * kNB * kTS)) * sizeof(double) + (size_t)2 * nrp * sizeof(int);
-    if (!factor) return kNB * kNB * sizeof(double) + step;
+    const size_t step = (2 * kMaxTouched * kTS + (factor ? 0 : (size_t)nw * kNB * kTS)) * sizeof(double) + (size_t)2 * nrp * sizeof(int);
+    if (!factor) return step;
     const size_t fixed = (2 * kNB * kNB + kTmetaInts / 2 + nw) * sizeof(double) + sizeof(int) * (nw + kNB);
     const size_t block = (size_t)kNB * rhs_ld(nrp) * sizeof(double);
     return fixed + (block > step ? block : step);
@@ -1268,12 +868,8 @@ size_t applyr_lds_bytes(int nrp, int nw, bool factor) {
 
 template <int THREADS, int MT, bool FACTOR>
 int launch_apply(const RhsArgs &ra, size_t lds, hipStream_t s) {
-#ifdef MPCX_APPLY_LDS  // the block in LDS (the older kernel, kept for comparison)
-    auto kernel = lu_apply_kernel<THREADS, MT, FACTOR>;
-#else
     auto kernel = lu_applyr_kernel<THREADS, MT, FACTOR>;
     lds = applyr_lds_bytes(ra.nrp, THREADS / 64, FACTOR);
-#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
