@@ -331,7 +331,16 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
     const int ldi = ipb | 1;                 // odd leading dimension of the staging area: [element][instance]
     double *stage = sm;
     double *pbuf = sm + (((size_t)ES * ldi + 1) & ~(size_t)1);  // pivot rows: [group][NCP]
-    const long long b0 = (long long)blockIdx.x * ipb;
+    // Two workgroups of 8 instances share every 128-byte line of an interleaved array, and consecutive workgroups go to
+    // different XCDs (different L2s): the two that share lines are made the ones 8 apart in launch order, neighbours on
+    // one XCD, so that the second finds the line in that XCD's L2.
+#ifndef MPCX_ROWS_NO_PAIRING
+    const long long slot = blockIdx.x >> 3, lblk = (((slot >> 1) << 3) + (blockIdx.x & 7)) * 2 + (slot & 1);
+#else
+    const long long lblk = blockIdx.x;
+#endif
+    const long long b0 = lblk * ipb;
+    if (b0 >= p.batch) return;  // (the grid is rounded up to whole groups of 16 workgroups)
     const int live = (p.batch - b0 < ipb) ? (int)(p.batch - b0) : ipb;
 
     // tr: the square matrix is staged transposed (element (row, col) lands where (col, row) would), so that the lanes'
@@ -470,11 +479,195 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
     }
 }
 
+// The same with TWO rows per lane and 16-lane groups (16 < NR <= 32: lane i keeps rows i and i + 16, the latter only
+// where it exists), four instances per wavefront instead of two.  What a step costs beside its multiply-adds -- the
+// pivot search, the vote, publishing and reading back the pivot row, the reciprocal -- is paid once per wavefront
+// whatever the number of rows a lane holds, the search stays inside one 16-lane row of the wavefront (four lane-to-lane
+// exchanges, no cross-row step), and a pivot row read back from LDS serves two rows.  The multipliers are taken as
+// a[k] x (1 / pivot), as nalgebra's elimination step scales its column.  A workgroup of 256 threads serves 16
+// instances (one access of the cooperative loads = one 128-byte line of an interleaved array) and stages the arrays in
+// pieces of CW columns.  RR: 0 (R is the right-hand side) or 1 (R is Gamma of a single-output plant, scaled by Q).
+template <int NR, int NRHS, int RR>
+__global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p) {
+    constexpr int G = 16, IPB = 16, LDI = IPB + 1, NC = NR + NRHS, NCP = (NC + 1) & ~1;
+    constexpr int CW = 5, CE = CW * NR;  // columns and elements staged at a time
+    static_assert(NR > G && NR <= 2 * G, "rows i and i + 16 in lane i");
+    static_assert(RR == 0 || RR == 1, "a right-hand side, or Gamma of a single-output plant");
+    extern __shared__ __align__(16) double sm[];
+    double *stage = sm;                                    // [CE][LDI]: [element of the piece][instance]
+    double *pbuf = sm + (((size_t)CE * LDI + 1) & ~(size_t)1);  // pivot rows: [group][NCP]
+    const int tid = threadIdx.x;
+    const long long b0 = (long long)blockIdx.x * IPB;
+    const int live = (p.batch - b0 < IPB) ? (int)(p.batch - b0) : IPB;
+    const int g = tid / G, i = tid % G, i1 = i + G < NR ? i + G : i;
+    const bool act0 = g < live, act1 = g < live && i + G < NR;
+    constexpr long long EH = (long long)NR * NR, ER = (long long)NR * NRHS;
+
+    // `count` elements of an array (E per instance) into the staging area, element `elem_of(idx)` at slot idx
+    auto load_piece = [&](const double *src, long long E, int count, auto elem_of) {
+        if (p.W > 1) {  // instance fastest: one access = the same element of the workgroup's 16 instances
+            const int inst = tid % IPB;
+            if (inst < live) {
+                const double *sp = src + elem_index(b0 + inst, 0, E, p.W);
+                for (int idx = tid / IPB; idx < count; idx += 256 / IPB) stage[idx * LDI + inst] = sp[(long long)elem_of(idx) * p.W];
+            }
+        } else {
+            for (int t = tid; t < live * count; t += 256) {
+                const int inst = t / count, idx = t - inst * count;
+                stage[idx * LDI + inst] = src[(b0 + inst) * E + elem_of(idx)];
+            }
+        }
+    };
+    double a0[NC], a1[NC];
+    // H, CW columns at a time (transposed: the columns of H^T are the rows of H)
+    const bool tr = p.transposed != 0;
+    auto load_h = [&](auto cc) {
+        constexpr int jc = decltype(cc)::value * CW, cw = NR - jc < CW ? NR - jc : CW;
+        load_piece(p.H, EH, cw * NR, [&](int idx) { const int j = jc + idx / NR, row = idx % NR; return tr ? row * NR + j : j * NR + row; });
+        lds_barrier();
+#pragma unroll
+        for (int jj = 0; jj < cw; ++jj) {
+            a0[jc + jj] = stage[(jj * NR + i) * LDI + g];
+            a1[jc + jj] = stage[(jj * NR + i1) * LDI + g];
+        }
+        lds_barrier();
+    };
+    for_each_index(load_h, std::make_integer_sequence<int, (NR + CW - 1) / CW>{});
+    const double q = RR ? p.Q[0] : 1.0;
+    auto load_r = [&](auto cc) {
+        constexpr int c0 = decltype(cc)::value * CW, cw = NRHS - c0 < CW ? NRHS - c0 : CW;
+        // right-hand side column c, row `row`: R[c NR + row], or Gamma[c][row] = R[row NRHS + c] (controller.rs:96, M^T W4)
+        load_piece(p.R, ER, cw * NR, [&](int idx) { const int c = c0 + idx / NR, row = idx % NR; return RR ? row * NRHS + c : c * NR + row; });
+        lds_barrier();
+#pragma unroll
+        for (int jj = 0; jj < cw; ++jj) {
+            const double r0 = stage[(jj * NR + i) * LDI + g], r1 = stage[(jj * NR + i1) * LDI + g];
+            a0[NR + c0 + jj] = RR ? 0.0 + r0 * q : r0;
+            a1[NR + c0 + jj] = RR ? 0.0 + r1 * q : r1;
+        }
+        lds_barrier();
+    };
+    for_each_index(load_r, std::make_integer_sequence<int, (NRHS + CW - 1) / CW>{});
+
+    const int lane = tid & 63, gbase = lane - i;  // first lane of this group within the wavefront
+    double *prow_buf = pbuf + (size_t)g * NCP;
+    bool done0 = false, done1 = false, failed = false;
+    int col0 = 0, col1 = 0;
+    double piv0 = 1.0, piv1 = 1.0;
+    auto step = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        double cand0 = -1.0, cand1 = -1.0;
+        if (act0 && !done0) {
+            const double x = fabs(a0[k]);
+            cand0 = (x == x) ? x : INFINITY;  // a NaN must be picked (and then fail), not skipped
+        }
+        if (act1 && !done1) {
+            const double x = fabs(a1[k]);
+            cand1 = (x == x) ? x : INFINITY;
+        }
+        double best = fmax(cand0, cand1);
+        best = fmax(best, dpp_f64<0xB1>(best));   // quad_perm [1,0,3,2]
+        best = fmax(best, dpp_f64<0x4E>(best));   // quad_perm [2,3,0,1]
+        best = fmax(best, dpp_f64<0x141>(best));  // row_half_mirror: quads pair up
+        best = fmax(best, dpp_f64<0x140>(best));  // row_mirror: halves of a row pair up
+        const unsigned v0 = (unsigned)(__ballot(cand0 == best && act0 && !done0) >> gbase) & 0xffffu;
+        const unsigned v1 = (unsigned)(__ballot(cand1 == best && act1 && !done1) >> gbase) & 0xffffu;
+        const int prow = v0 ? __ffs((int)v0) - 1 : v1 ? G + __ffs((int)v1) - 1 : 0;  // ties: the lowest row
+        if (!(best > 0.0) || !isfinite(best)) failed = true;  // zero or non-finite pivot: the reference's inversion error
+        const bool is_piv0 = (i == prow), is_piv1 = (i + G == prow);
+        constexpr int J0 = k & ~1;  // 16-byte pairs: an odd k republishes column k - 1 as well (never read)
+        if (is_piv0) {
+#pragma unroll
+            for (int j = J0; j < NC; j += 2)
+                *(double2 *)(prow_buf + j) = make_double2(a0[j], j + 1 < NC ? a0[j + 1 < NC ? j + 1 : j] : 0.0);
+        } else if (is_piv1) {
+#pragma unroll
+            for (int j = J0; j < NC; j += 2)
+                *(double2 *)(prow_buf + j) = make_double2(a1[j], j + 1 < NC ? a1[j + 1 < NC ? j + 1 : j] : 0.0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double inv = 1.0 / prow_buf[k];
+        if (is_piv0 && !failed) { done0 = true; col0 = k; piv0 = a0[k]; }
+        if (is_piv1 && !failed) { done1 = true; col1 = k; piv1 = a1[k]; }
+        const double m0 = (act0 && !is_piv0 && !failed) ? a0[k] * inv : 0.0;
+        const double m1 = (act1 && !is_piv1 && !failed) ? a1[k] * inv : 0.0;
+        // a[j] -= m P[j] for j > k, the pivot row read back in chunks of CH pairs
+        constexpr int CH = 5;
+#pragma unroll
+        for (int j0 = (k + 1) & ~1; j0 < NC; j0 += 2 * CH) {
+            double2 t[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (j0 + 2 * u < NC) t[u] = *(const double2 *)(prow_buf + j0 + 2 * u);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = j0 + 2 * u;
+                if (j > k && j < NC) {
+                    a0[j < NC ? j : 0] -= m0 * t[u].x;
+                    a1[j < NC ? j : 0] -= m1 * t[u].x;
+                }
+                if (j + 1 > k && j + 1 < NC) {
+                    a0[j + 1 < NC ? j + 1 : 0] -= m0 * t[u].y;
+                    a1[j + 1 < NC ? j + 1 : 0] -= m1 * t[u].y;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for_each_index(step, std::make_integer_sequence<int, NR>{});
+    // the row that was the pivot of step k holds unknown k: x[k][c] = a[row][NR + c] / a[row][k]
+    const double sign = p.negate ? -1.0 : 1.0;
+    const double inv0 = 1.0 / piv0, inv1 = 1.0 / piv1;
+    const int row0 = failed ? i : col0, row1 = failed ? i + G : col1;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (p.info && i == 0 && act0) p.info[b0 + g] = failed ? 1 : 0;
+    lds_barrier();
+    auto store_x = [&](auto cc) {
+        constexpr int c0 = decltype(cc)::value * CW, cw = NRHS - c0 < CW ? NRHS - c0 : CW;
+#pragma unroll
+        for (int jj = 0; jj < cw; ++jj) {
+            if (act0) stage[(jj * NR + row0) * LDI + g] = failed ? nan : sign * (a0[NR + c0 + jj] * inv0);
+            if (act1) stage[(jj * NR + row1) * LDI + g] = failed ? nan : sign * (a1[NR + c0 + jj] * inv1);
+        }
+        lds_barrier();
+        constexpr int count = cw * NR, e0 = c0 * NR;  // X is NR x NRHS, column-major: the piece is one contiguous run of elements
+        if (p.W > 1) {
+            const int inst = tid % IPB;
+            if (inst < live) {
+                double *xp = p.X + elem_index(b0 + inst, 0, ER, p.W);
+                for (int idx = tid / IPB; idx < count; idx += 256 / IPB) xp[(long long)(e0 + idx) * p.W] = stage[idx * LDI + inst];
+            }
+        } else {
+            for (int t = tid; t < live * count; t += 256) {
+                const int inst = t / count, idx = t - inst * count;
+                p.X[(b0 + inst) * ER + e0 + idx] = stage[idx * LDI + inst];
+            }
+        }
+        lds_barrier();
+    };
+    for_each_index(store_x, std::make_integer_sequence<int, (NRHS + CW - 1) / CW>{});
+}
+
+template <int NR, int NRHS, int RR>
+int launch_rows2(const SolveArgs &a, hipStream_t s) {
+    constexpr int NC = NR + NRHS, NCP = (NC + 1) & ~1, CE = 5 * NR;
+    const long long blocks = (a.batch + 15) / 16;
+    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    const size_t lds = ((((size_t)CE * 17 + 1) & ~(size_t)1) + (size_t)16 * NCP) * sizeof(double);
+    hipLaunchKernelGGL((solve_rows2_kernel<NR, NRHS, RR>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}
+
 template <int NR, int NRHS, int RR>
 int launch_rows(const SolveArgs &a, hipStream_t s) {
     constexpr int NC = NR + NRHS, NCP = (NC + 1) & ~1, ES = NR * (NR > NRHS ? NR : NRHS);
     const int ipb = 8;  // 64-byte runs in the interleaved layouts; measured: 4 and 16 instances are 2 % and 7 % slower
-    const long long blocks = (a.batch + ipb - 1) / ipb;
+    const long long blocks = ((a.batch + ipb - 1) / ipb + 15) / 16 * 16;  // whole groups of 16: see the kernel's workgroup numbering
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     const size_t lds = ((((size_t)ES * (ipb | 1) + 1) & ~(size_t)1) + (size_t)ipb * NCP) * sizeof(double);
     hipLaunchKernelGGL((solve_rows_kernel<NR, NRHS, RR>), dim3((unsigned)blocks), dim3(ipb * 32), lds, s, a, ipb);
@@ -528,6 +721,11 @@ int launch_solve(const SolveArgs &a, hipStream_t s) {
     if (a.nrow == 3) return launch_tiny<3>(a, s);
     if (a.nrow == 4) return launch_tiny<4>(a, s);
     // the reference's horizon with rows in registers: gain of a single-output plant, and the solve
+    // (a single right-hand side: two rows per lane, 2.86 -> 2.57 ms on 2^20 systems; with 20 right-hand sides the
+    //  80 row elements of a lane leave too few wavefronts resident and the one-row kernel is twice as fast)
+#ifndef MPCX_ROWS1  // (-DMPCX_ROWS1: the one-row-per-lane kernel, for comparison)
+    if (a.nrow == 20 && a.nrhs == 1 && !a.Q) return launch_rows2<20, 1, 0>(a, s);
+#endif
     if (a.nrow == 20 && a.nrhs == 20 && a.Q && a.r == 1 && a.R != a.X) return launch_rows<20, 20, 1>(a, s);
     // (in place is fine here: a workgroup reads the right-hand sides of its own instances into LDS before it writes them)
     if (a.nrow == 20 && a.nrhs == 1 && !a.Q) return launch_rows<20, 1, 0>(a, s);
