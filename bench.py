@@ -264,14 +264,24 @@ def main():
                                metric=metric, unit=unit, check_buf=check_buf, info=info, hessian=hessian, h_only=h_only)
 
     def event_ms(fn, steps):
-        """Mean duration of fn() over `steps` calls, HIP events on the launch stream around each call."""
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        for a, b in ev:
-            a.record(stream)
+        """Mean duration of fn() over `steps` back-to-back calls: one HIP event on the launch stream before the first and
+        one after the last (an event between two launches makes the second wait for the first one's write-back to
+        memory and adds 12-25 us to each step; MPCX_BENCH_EVENTS_PER_STEP=1 brackets every call instead)."""
+        if PER_STEP_EVENTS:
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            for a, b in ev:
+                a.record(stream)
+                fn()
+                b.record(stream)
+            torch.cuda.synchronize()
+            return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(steps):
             fn()
-            b.record(stream)
+        b.record(stream)
         torch.cuda.synchronize()
-        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return a.elapsed_time(b) / steps
 
     case = make_case(args.workload, args.op, args.batch, args.interleave, args.f, args.v, args.hessian)
     n, m, r, f, v, T, il, per_gpu, count = case.n, case.m, case.r, case.f, case.v, case.T, case.il, case.per_gpu, case.count
@@ -286,15 +296,24 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if PER_STEP_EVENTS:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    else:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))]
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
+    if PER_STEP_EVENTS:
+        for a, b in ev:
+            a.record(stream)
+            step()
+            b.record(stream)
+    else:
+        ev[0][0].record(stream)
+        for _ in range(args.steps):
+            step()
+        ev[0][1].record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # HIP events on the launch stream
+    kernel_ms = float(sum(a.elapsed_time(b) for a, b in ev)) / args.steps  # HIP events on the launch stream
 
     # ---- hessian_algo = CONTRACT: the dominant kernel is the FP64-MFMA contraction; time it on its own ----
     mfma_ms = None
@@ -472,6 +491,7 @@ ALSO = (("msd", "qp", 0, 0, 0), ("quadrotor", "qp", 0, 0, 0), ("long", "qp", 0, 
         ("two_mass", "solve", 0, 0, 0), ("two_mass", "gain", 0, 0, 0), ("two_mass", "loop", 0, 0, 0),
         ("quadrotor", "loop", 0, 0, 0), ("quadrotor", "gain", 0, 0, 0), ("long", "gain", 0, 0, 0),
         ("two_mass", "gain_rows", 0, 0, 0), ("quadrotor", "gain_rows", 0, 0, 0), ("long", "gain_rows", 0, 0, 0))
+PER_STEP_EVENTS = os.environ.get("MPCX_BENCH_EVENTS_PER_STEP", "0") == "1"
 ALSO_BUDGET_S = 120.0  # the extras take about 25 s; beyond this something has regressed and the run fails
 
 def _solver_roofline(case, op, ms, hbm_roofline):

@@ -47,7 +47,9 @@ struct LaneOut {
 // UNI: every lane of a wavefront lies in the same interleave tile (W is a multiple of 64, or W >= batch), so the
 // tile offset is wave-uniform and each access is "scalar base + 32-bit lane offset".
 // OUT: 0 = test the output pointers at run time; 15 = all four outputs are present (no tests in the stream).
-template <int N, int M, int R, bool UNI, int F, int V, int OUT, bool PAD = false>
+// LAG: held inputs (3 <= v < f, checked by the launcher) with the border blocks of H through the lag factorisation
+// described at the sweep; a separate instantiation, so that the other horizons keep their registers and schedule.
+template <int N, int M, int R, bool UNI, int F, int V, int OUT, bool PAD = false, bool LAG = false>
 __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(const double *__restrict__ gA, const double *__restrict__ gB,
                                                              const double *__restrict__ gC,
                                                              const double *__restrict__ gW3,
@@ -309,14 +311,199 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
     // column block is kept (registers, or the LDS slots z no longer needs) and updated in place, and every column
     // is stored top to bottom, so the stores walk memory in order.  The other blocks are summed directly over
     // the rows i2 >= max(a, b), with S_j = G_0 + ... + G_j standing in for the held-input (last) column.
+    // With held inputs (v < f) a direct sum has up to f - v + 2 terms and there are 4 v of them.  They are correlations of
+    // the Markov sequence with itself (or with its running sums) at lag d, and G_(k+d) = (C A^k) A^d B factors the lag out:
+    //   H[a][v-1] = sum_k G_(k+d)^T Q S_k = B^T (A^T)^d Zc1,   Zc1 = sum_{k <= f-v}   (C A^k)^T Q S_k,   d = v-1-a >= 1
+    //   H[a][v-2] = sum_k G_(k+d)^T Q G_k = B^T (A^T)^d Zc2,   Zc2 = sum_{k <= f-v+1} (C A^k)^T Q G_k,   d = v-2-a >= 0
+    //   H[v-1][b] = sum_k S_k^T Q G_(k+d) = Yr1 (A^d B),       Yr1 = sum_{k <= f-v}   S_k^T Q (C A^k),   d = v-1-b >= 1
+    //   H[v-2][b] = sum_k G_k^T Q G_(k+d) = Yr2 (A^d B),       Yr2 = sum_{k <= f-v+1} G_k^T Q (C A^k),   d = v-2-b >= 0
+    // so the four n x m accumulators are formed once (f - v + 2 steps) and every border block costs one step of an
+    // n x m recurrence and an m x n x m product; only the corner H[v-1][v-1] = sum_k S_k^T Q S_k stays a direct sum.
     if (wH) {
         const unsigned lb = keep_local(lane_byte);
         double hreg[STATIC ? V * M * M : 1];
 #define HP(a, i, j) \
     (*(STATIC ? &hreg[STATIC ? (((a) * M + (i)) * M + (j)) : 0] : &lds[(zbase + ((a) * m + (i)) * m + (j)) * kLaneBlock + tid]))
         char *bH = BASE(p.H, (long long)VM * VM);
+        // column block bb of H from HP, top to bottom, with W3 added
+        auto store_col = [&](int bb) {
 #pragma unroll
-        for (int bb = (STATIC ? V : v) - 1; bb >= 0; --bb) {
+            for (int j = 0; j < M; ++j) {
+                if (!IN_M(j)) continue;
+                char *ph = bH + (long long)(bb * m + j) * VM * stride;
+                const double *w3 = gW3 + (long long)(bb * m + j) * VM;
+#pragma unroll
+                for (int aa = 0; aa < (STATIC ? V : v); ++aa)
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+                        if (!IN_M(i)) continue;
+                        HERE(ph) = HP(aa, i, j) + w3[aa * m + i];
+                        ph += stride;
+                    }
+            }
+        };
+        static_assert(!(LAG && F > 0), "the lag factorisation takes run-time horizons");
+        constexpr bool lagged = LAG;
+        double Yr1[M][N], Yr2[M][N], wd[N][M];  // (lagged) the row accumulators and A^d B, d = v-2-bb
+        int bb_first = v - 1;
+        if (lagged) {
+            const int L = f - v;
+            double Zc1[N][M], Zc2[N][M], cr[M][M], S[R][M], CA[R][N];
+#pragma unroll
+            for (int q = 0; q < N; ++q)
+#pragma unroll
+                for (int c = 0; c < M; ++c) {
+                    Zc1[q][c] = 0.0;
+                    Zc2[q][c] = 0.0;
+                    Yr1[c][q] = 0.0;
+                    Yr2[c][q] = 0.0;
+                    wd[q][c] = Bm[q][c];
+                }
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) cr[i][j] = 0.0;
+#pragma unroll
+            for (int a = 0; a < R; ++a) {
+#pragma unroll
+                for (int c = 0; c < M; ++c) S[a][c] = 0.0;
+#pragma unroll
+                for (int q = 0; q < N; ++q) CA[a][q] = Cm[a][q];
+            }
+            for (int k = 0; k <= L + 1; ++k) {
+                const bool in = (k <= L);  // the sums with S stop one term earlier
+                double g[R][M], qg[R][M], qtg[R][M];
+#pragma unroll
+                for (int a = 0; a < R; ++a)
+#pragma unroll
+                    for (int c = 0; c < M; ++c) {
+                        g[a][c] = (IN_R(a) && IN_M(c)) ? LG(k, a, c) : 0.0;
+                        if (in) S[a][c] += g[a][c];
+                    }
+                auto add_term = [&](const double (&x)[R][M], double (&Zc)[N][M], double (&Yr)[M][N]) {
+#pragma unroll
+                    for (int a = 0; a < R; ++a)
+#pragma unroll
+                        for (int c = 0; c < M; ++c) {
+                            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                            for (int q = 0; q < R; ++q) {
+                                s1 += Q[a][q] * x[q][c];
+                                s2 += Q[q][a] * x[q][c];
+                            }
+                            qg[a][c] = s1;   // Q x
+                            qtg[a][c] = s2;  // Q^T x
+                        }
+#pragma unroll
+                    for (int q = 0; q < N; ++q)
+#pragma unroll
+                        for (int c = 0; c < M; ++c)
+#pragma unroll
+                            for (int a = 0; a < R; ++a) {
+                                Zc[q][c] += CA[a][q] * qg[a][c];
+                                Yr[c][q] += qtg[a][c] * CA[a][q];
+                            }
+                };
+                add_term(g, Zc2, Yr2);
+                if (in) {
+                    add_term(S, Zc1, Yr1);  // (leaves qg = Q S_k)
+#pragma unroll
+                    for (int i = 0; i < M; ++i)
+#pragma unroll
+                        for (int j = 0; j < M; ++j)
+#pragma unroll
+                            for (int a = 0; a < R; ++a) cr[i][j] += S[a][i] * qg[a][j];
+                }
+                double CAn[R][N];
+#pragma unroll
+                for (int a = 0; a < R; ++a)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        double sc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < N; ++q) sc += CA[a][q] * A[q][j];
+                        CAn[a][j] = sc;
+                    }
+#pragma unroll
+                for (int a = 0; a < R; ++a)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) CA[a][j] = CAn[a][j];
+            }
+            // Z <- A^T Z
+            auto lag_step = [&](double (&Z)[N][M]) {
+                double Zn[N][M];
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+#pragma unroll
+                    for (int c = 0; c < M; ++c) {
+                        double sz = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) sz += A[j][q] * Z[j][c];
+                        Zn[q][c] = sz;
+                    }
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+#pragma unroll
+                    for (int c = 0; c < M; ++c) Z[q][c] = Zn[q][c];
+            };
+            // HP(aa) <- B^T Z
+            auto put_col_block = [&](int aa, const double (&Z)[N][M]) {
+#pragma unroll
+                for (int i = 0; i < M; ++i)
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        double sb = 0.0;
+#pragma unroll
+                        for (int q = 0; q < N; ++q) sb += Bm[q][i] * Z[q][j];
+                        if (IN_M(i) && IN_M(j)) HP(aa, i, j) = sb;
+                    }
+            };
+            // column v-1: the corner, then lags 1 .. v-1 going up
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j)
+                    if (IN_M(i) && IN_M(j)) HP(v - 1, i, j) = cr[i][j];
+            for (int aa = v - 2; aa >= 0; --aa) {
+                lag_step(Zc1);
+                put_col_block(aa, Zc1);
+            }
+            store_col(v - 1);
+            // column v-2: lags 0 .. v-2 going up; its last block row is H[v-1][v-2] = Yr1 (A B)
+            for (int aa = v - 2; aa >= 0; --aa) {
+                put_col_block(aa, Zc2);
+                lag_step(Zc2);
+            }
+            {
+                double wn[N][M];
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+#pragma unroll
+                    for (int c = 0; c < M; ++c) {
+                        double sw = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) sw += A[q][j] * wd[j][c];
+                        wn[q][c] = sw;
+                    }
+#pragma unroll
+                for (int i = 0; i < M; ++i)
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        double sy = 0.0;
+#pragma unroll
+                        for (int q = 0; q < N; ++q) sy += Yr1[i][q] * wn[q][j];
+                        if (IN_M(i) && IN_M(j)) HP(v - 1, i, j) = sy;
+                    }
+#pragma unroll
+                for (int q = 0; q < N; ++q)
+#pragma unroll
+                    for (int c = 0; c < M; ++c) wd[q][c] = wn[q][c];
+            }
+            store_col(v - 2);
+            bb_first = v - 3;
+        }
+#pragma unroll
+        for (int bb = (STATIC ? V - 1 : bb_first); bb >= 0; --bb) {
 #pragma unroll
             for (int aa = 0; aa < (STATIC ? V : v); ++aa) {
                 double acc[M][M];
@@ -342,6 +529,36 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                             for (int a = 0; a < R; ++a)
                                 if (IN_R(a)) t += LG(f - 1 - aa, a, i) * qg[a][j];
                             acc[i][j] = t;
+                        }
+                } else if (lagged) {
+                    // (bb <= v-3 here) block rows v-2 and v-1: Yr2 (A^d B) and Yr1 (A^(d+1) B), d = v-2-bb
+                    if (aa == v - 1) {
+                        double wn[N][M];
+#pragma unroll
+                        for (int q = 0; q < N; ++q)
+#pragma unroll
+                            for (int c = 0; c < M; ++c) {
+                                double sw = 0.0;
+#pragma unroll
+                                for (int j = 0; j < N; ++j) sw += A[q][j] * wd[j][c];
+                                wn[q][c] = sw;
+                            }
+#pragma unroll
+                        for (int q = 0; q < N; ++q)
+#pragma unroll
+                            for (int c = 0; c < M; ++c) wd[q][c] = wn[q][c];
+                    }
+#pragma unroll
+                    for (int i = 0; i < M; ++i)
+#pragma unroll
+                        for (int j = 0; j < M; ++j) {
+                            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                            for (int q = 0; q < N; ++q) {
+                                s1 += Yr1[i][q] * wd[q][j];
+                                s2 += Yr2[i][q] * wd[q][j];
+                            }
+                            acc[i][j] = aa == v - 1 ? s1 : s2;
                         }
                 } else {
                     const bool la = (aa == v - 1), lbk = (bb == v - 1);
@@ -395,20 +612,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                     for (int j = 0; j < M; ++j)
                         if (IN_M(i) && IN_M(j)) HP(aa, i, j) = acc[i][j];
             }
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                if (!IN_M(j)) continue;
-                char *ph = bH + (long long)(bb * m + j) * VM * stride;
-                const double *w3 = gW3 + (long long)(bb * m + j) * VM;
-#pragma unroll
-                for (int aa = 0; aa < (STATIC ? V : v); ++aa)
-#pragma unroll
-                    for (int i = 0; i < M; ++i) {
-                        if (!IN_M(i)) continue;
-                        HERE(ph) = HP(aa, i, j) + w3[aa * m + i];
-                        ph += stride;
-                    }
-            }
+            store_col(bb);
         }
 #undef HP
     }
@@ -423,15 +627,15 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
 #undef IN_R
 }
 
-template <int N, int M, int R, bool UNI, int F, int V, int OUT, bool PAD = false>
+template <int N, int M, int R, bool UNI, int F, int V, int OUT, bool PAD = false, bool LAG = false>
 int launch_k(const QpArgs &a, size_t lds_bytes, unsigned blocks, hipStream_t s) {
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)qp_lane_kernel<N, M, R, UNI, F, V, OUT, PAD>,
+        hipError_t e = hipFuncSetAttribute((const void *)qp_lane_kernel<N, M, R, UNI, F, V, OUT, PAD, LAG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
     LaneOut o{a.Phi, a.Gamma, a.H, a.fvec};
-    hipLaunchKernelGGL((qp_lane_kernel<N, M, R, UNI, F, V, OUT, PAD>), dim3(blocks), dim3(kLaneBlock), lds_bytes, s, a.A, a.B, a.C,
+    hipLaunchKernelGGL((qp_lane_kernel<N, M, R, UNI, F, V, OUT, PAD, LAG>), dim3(blocks), dim3(kLaneBlock), lds_bytes, s, a.A, a.B, a.C,
                        a.W3, a.W4, a.x0, a.ref, o, a.batch, a.W, a.f, a.v, a.n, a.m, a.r);
     return (int)hipGetLastError();
 }
@@ -456,6 +660,11 @@ int launch_one(const QpArgs &a, hipStream_t s) {
     }
     const size_t lds_bytes = lane_lds_bytes(a);
     if (lds_bytes > 160 * 1024) return MPCX_ERR_UNSUPPORTED;
+    if (a.H && a.v >= 3 && a.f > a.v) {  // held inputs: H's border blocks through the lag factorisation
+        if (uni && all) return launch_k<N, M, R, true, 0, 0, 15, PAD, true>(a, lds_bytes, (unsigned)blocks, s);
+        return uni ? launch_k<N, M, R, true, 0, 0, 0, PAD, true>(a, lds_bytes, (unsigned)blocks, s)
+                   : launch_k<N, M, R, false, 0, 0, 0, PAD, true>(a, lds_bytes, (unsigned)blocks, s);
+    }
     if (uni && all) return launch_k<N, M, R, true, 0, 0, 15, PAD>(a, lds_bytes, (unsigned)blocks, s);
     return uni ? launch_k<N, M, R, true, 0, 0, 0, PAD>(a, lds_bytes, (unsigned)blocks, s)
                : launch_k<N, M, R, false, 0, 0, 0, PAD>(a, lds_bytes, (unsigned)blocks, s);

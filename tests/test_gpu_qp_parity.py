@@ -49,6 +49,28 @@ def test_lane_kernel_shapes_and_held_input(ctx, n, m, r, f, v):
             assert_close(got[k], want[k], f"n{n} m{m} r{r} f{f} v{v} W={il} {k}")
 
 
+@pytest.mark.parametrize("n,m,r", [(4, 1, 1), (2, 1, 1), (4, 2, 2), (6, 2, 2), (3, 2, 1), (4, 1, 2), (5, 2, 2), (6, 3, 3), (2, 3, 1)])
+@pytest.mark.parametrize("f,v,rho", [(4, 3, 0.9), (30, 10, 0.9), (60, 5, 0.97), (40, 30, 1.0), (25, 12, 1.05), (33, 3, 0.5)])
+def test_lane_kernel_held_inputs_border_blocks(ctx, n, m, r, f, v, rho):
+    """Held inputs (3 <= v < f) on the one-lane kernel: the last two block rows and columns of H are correlations of the
+    Markov sequence at a lag, which the kernel evaluates through accumulators formed once and an n x m recurrence per
+    block instead of the direct sums of controller.rs:63-93.  Windows from 2 to 57 steps, slowly decaying, marginal and
+    growing plants, a non-symmetric Q; H alone must equal H of the full call bit for bit."""
+    rng = np.random.default_rng(7000 + 1000 * n + 100 * m + 10 * r + f + v)
+    batch = 96
+    A, B, C = random_stable_plants(rng, batch, n, m, r, rho=rho)
+    data = dict(A=A, B=B, C=C, W3=rng.standard_normal((v * m, v * m)), Q=rng.standard_normal((r, r)),
+                x0=rng.standard_normal((batch, n)), ref=rng.standard_normal((batch, f * r)), f=f, v=v)
+    want = oracle_qp(orc, data)
+    for il in (0, 1, 64):
+        got = _run(ctx, data, il)
+        for k in ("Phi", "Gamma", "H", "fvec"):
+            assert_close(got[k], want[k], f"n{n} m{m} r{r} f{f} v{v} rho={rho} W={il} {k}")
+    full = _run(ctx, data, 64)
+    part = _run(ctx, data, 64, want=("H",))
+    assert np.array_equal(part["H"], full["H"]), "H alone differs from the full call"
+
+
 @pytest.mark.parametrize("n,m,r", [(5, 2, 2), (3, 2, 2), (2, 3, 1), (6, 1, 3), (1, 2, 2), (5, 1, 2), (2, 1, 2), (6, 3, 3),
                                    (1, 3, 3), (4, 3, 2)])
 @pytest.mark.parametrize("f,v", [(20, 20), (9, 4), (5, 1)])
