@@ -141,7 +141,10 @@ int mpcx_set_option(mpcx_ctx *ctx, int option, int64_t value);
  * Markov vectors in a device workspace the context owns (4 m f r + 2 f r doubles per instance in flight, at most 8 GiB at a
  * time, see mpcx_reserve), limited only by 2 n (m + r) + n + r m <= 20 480 doubles of recurrence state.  MPCX_WEIGHTS_DENSE
  * and MPCX_HESSIAN_CONTRACT keep on-chip limits ((f r)(m + 1) resp. the Markov vectors in LDS) and return
- * MPCX_ERR_UNSUPPORTED beyond them.  Exact zeros of W3 are skipped: the
+ * MPCX_ERR_UNSUPPORTED beyond them.  H is never formed as the reference's dense triple product: its blocks are summed
+ * along block diagonals, and with held inputs (v < f) the one-lane kernels evaluate the blocks of the last two block rows
+ * and columns through G_(k+d) = (C A^k) A^d B with the sums over k formed once; every form agrees with the dense product
+ * to rounding (the tests hold 1e-10, relative, Frobenius, per instance).  Exact zeros of W3 are skipped: the
  * band structure of W3 is measured on the device by each call (W3 as Controller::new builds it is block tridiagonal,
  * controller.rs:149-177).  The context's scratch is shared by all its calls: do not run two calls of one context
  * concurrently on different streams.

@@ -23,9 +23,9 @@ CASES = {
     "rollout_msd": ("rollout:msd:65536:20:20", r"rollout_lane_kernel"),
     "rollout_two_mass": ("rollout:two_mass:1048576:20:20", r"rollout_lane_kernel"),
     "rollout_quadrotor": ("rollout:quadrotor:16384:50:50", r"rollout_group_kernel"),
-    "solve_two_mass": ("solve:two_mass:1048576:20:20", r"solve_rows_kernel"),
-    "gain_two_mass": ("gain:two_mass:1048576:20:20", r"solve_rows_kernel"),
-    "gain_rows_two_mass": ("gain_rows:two_mass:1048576:20:20", r"solve_rows_kernel|rows_lane_kernel|unit_columns_kernel"),
+    "solve_two_mass": ("solve:two_mass:1048576:20:20", r"solve_rows2?_kernel"),
+    "gain_two_mass": ("gain:two_mass:1048576:20:20", r"solve_rows2?_kernel"),
+    "gain_rows_two_mass": ("gain_rows:two_mass:1048576:20:20", r"solve_rows2?_kernel|rows_lane_kernel|unit_columns_kernel"),
     "loop_two_mass": ("loop:two_mass:1048576:20:20", r"closed_loop_lane_kernel"),
     "loop_quadrotor": ("loop:quadrotor:16384:50:50", r"closed_loop_affine_kernel|closed_loop_rows_kernel|closed_loop_group_kernel"),
     "gain_quadrotor": ("gain:quadrotor:16384:50:50", r"lu_\w+"),
