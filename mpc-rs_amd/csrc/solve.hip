@@ -487,10 +487,8 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
 // a[k] x (1 / pivot), as nalgebra's elimination step scales its column.  A workgroup of 256 threads serves 16
 // instances (one access of the cooperative loads = one 128-byte line of an interleaved array) and stages the arrays in
 // pieces of CW columns.  RR: 0 (R is the right-hand side) or 1 (R is Gamma of a single-output plant, scaled by Q).
-// NT, cg: the call's right-hand sides number NT and this launch takes columns cg .. cg + NRHS - 1 of them (the gain's 20
-// columns go in two launches of 10: 60 row elements per lane instead of 80).
-template <int NR, int NRHS, int RR, int NT = NRHS>
-__global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p, int cg) {
+template <int NR, int NRHS, int RR>
+__global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p) {
     constexpr int G = 16, IPB = 16, LDI = IPB + 1, NC = NR + NRHS, NCP = (NC + 1) & ~1;
     constexpr int CW = 5, CE = CW * NR;  // columns and elements staged at a time
     static_assert(NR > G && NR <= 2 * G, "rows i and i + 16 in lane i");
@@ -503,7 +501,7 @@ __global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p, int cg) {
     const int live = (p.batch - b0 < IPB) ? (int)(p.batch - b0) : IPB;
     const int g = tid / G, i = tid % G, i1 = i + G < NR ? i + G : i;
     const bool act0 = g < live, act1 = g < live && i + G < NR;
-    constexpr long long EH = (long long)NR * NR, ER = (long long)NR * NT;
+    constexpr long long EH = (long long)NR * NR, ER = (long long)NR * NRHS;
 
     // `count` elements of an array (E per instance) into the staging area, element `elem_of(idx)` at slot idx
     auto load_piece = [&](const double *src, long long E, int count, auto elem_of) {
@@ -539,7 +537,7 @@ __global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p, int cg) {
     auto load_r = [&](auto cc) {
         constexpr int c0 = decltype(cc)::value * CW, cw = NRHS - c0 < CW ? NRHS - c0 : CW;
         // right-hand side column c, row `row`: R[c NR + row], or Gamma[c][row] = R[row NRHS + c] (controller.rs:96, M^T W4)
-        load_piece(p.R, ER, cw * NR, [&](int idx) { const int c = cg + c0 + idx / NR, row = idx % NR; return RR ? row * NT + c : c * NR + row; });
+        load_piece(p.R, ER, cw * NR, [&](int idx) { const int c = c0 + idx / NR, row = idx % NR; return RR ? row * NRHS + c : c * NR + row; });
         lds_barrier();
 #pragma unroll
         for (int jj = 0; jj < cw; ++jj) {
@@ -637,8 +635,7 @@ __global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p, int cg) {
             if (act1) stage[(jj * NR + row1) * LDI + g] = failed ? nan : sign * (a1[NR + c0 + jj] * inv1);
         }
         lds_barrier();
-        constexpr int count = cw * NR;
-        const int e0 = (cg + c0) * NR;  // X is NR x NT, column-major: the piece is one contiguous run of elements
+        constexpr int count = cw * NR, e0 = c0 * NR;  // X is NR x NRHS, column-major: the piece is one contiguous run of elements
         if (p.W > 1) {
             const int inst = tid % IPB;
             if (inst < live) {
@@ -656,19 +653,14 @@ __global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p, int cg) {
     for_each_index(store_x, std::make_integer_sequence<int, (NRHS + CW - 1) / CW>{});
 }
 
-template <int NR, int NRHS, int RR, int NT = NRHS>
+template <int NR, int NRHS, int RR>
 int launch_rows2(const SolveArgs &a, hipStream_t s) {
-    static_assert(NT % NRHS == 0, "whole launches");
     constexpr int NC = NR + NRHS, NCP = (NC + 1) & ~1, CE = 5 * NR;
     const long long blocks = (a.batch + 15) / 16;
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     const size_t lds = ((((size_t)CE * 17 + 1) & ~(size_t)1) + (size_t)16 * NCP) * sizeof(double);
-    for (int cg = 0; cg < NT; cg += NRHS) {
-        hipLaunchKernelGGL((solve_rows2_kernel<NR, NRHS, RR, NT>), dim3((unsigned)blocks), dim3(256), lds, s, a, cg);
-        const int e = (int)hipGetLastError();
-        if (e) return e;
-    }
-    return 0;
+    hipLaunchKernelGGL((solve_rows2_kernel<NR, NRHS, RR>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+    return (int)hipGetLastError();
 }
 
 template <int NR, int NRHS, int RR>
@@ -733,9 +725,6 @@ int launch_solve(const SolveArgs &a, hipStream_t s) {
     //  80 row elements of a lane leave too few wavefronts resident and the one-row kernel is twice as fast)
 #ifndef MPCX_ROWS1  // (-DMPCX_ROWS1: the one-row-per-lane kernel, for comparison)
     if (a.nrow == 20 && a.nrhs == 1 && !a.Q) return launch_rows2<20, 1, 0>(a, s);
-#endif
-#ifdef MPCX_GAIN_ROWS2
-    if (a.nrow == 20 && a.nrhs == 20 && a.Q && a.r == 1 && a.R != a.X) return launch_rows2<20, MPCX_GAIN_ROWS2, 1, 20>(a, s);
 #endif
     if (a.nrow == 20 && a.nrhs == 20 && a.Q && a.r == 1 && a.R != a.X) return launch_rows<20, 20, 1>(a, s);
     // (in place is fine here: a workgroup reads the right-hand sides of its own instances into LDS before it writes them)
