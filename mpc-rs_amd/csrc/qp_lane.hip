@@ -237,40 +237,49 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
     }
 
     // ---- fvec = Gamma^T z (before H, which reuses z's LDS slots) ----
+    // Block k of Gamma^T z is sum_{i >= k} G_(i-k)^T z_i with G_(i-k)^T = B^T (A^T)^(i-k) C^T, i.e. the adjoint recursion
+    // p_k = C^T z_k + A^T p_(k+1) (p_f = 0) read out through B^T: fvec block k = B^T p_k for k < v-1, and the held-input
+    // block (S in place of G) is B^T (p_(v-1) + ... + p_(f-1)).  f steps of an n-vector in registers with one read of z
+    // per step replace v f / 2 dependent pairs of LDS reads (run-time horizons) or as many multiply-adds.
     if (wf) {
         const unsigned lb = keep_local(lane_byte);
-        char *pf = BASE(p.fvec, VM);
+        char *bf = BASE(p.fvec, VM);
+        double pv[N], ps[N];
 #pragma unroll
-        for (int k = 0; k < (STATIC ? V : v); ++k) {
-            const bool last = (k == v - 1);
-            double acc[M], run[R][M];
+        for (int j = 0; j < N; ++j) {
+            pv[j] = 0.0;
+            ps[j] = 0.0;
+        }
 #pragma unroll
-            for (int c = 0; c < M; ++c) acc[c] = 0.0;
+        for (int k = (STATIC ? F : f) - 1; k >= 0; --k) {
+            double zk[R], pn[N];
 #pragma unroll
-            for (int a = 0; a < R; ++a)
+            for (int a = 0; a < R; ++a) zk[a] = IN_R(a) ? LZ(k, a) : 0.0;
 #pragma unroll
-                for (int c = 0; c < M; ++c) run[a][c] = 0.0;
+            for (int j = 0; j < N; ++j) {
+                double sp = 0.0;
 #pragma unroll
-            for (int i = (STATIC ? 0 : k); i < (STATIC ? F : f); ++i) {
-                if (STATIC && i < k) continue;  // constant trip count, so that the nest unrolls fully
+                for (int a = 0; a < R; ++a) sp += Cm[a][j] * zk[a];
 #pragma unroll
-                for (int a = 0; a < R; ++a) {
-                    if (!IN_R(a)) continue;
-                    const double z = LZ(i, a);
-#pragma unroll
-                    for (int c = 0; c < M; ++c) {
-                        if (!IN_M(c)) continue;
-                        const double g = LG(i - k, a, c);
-                        run[a][c] += g;
-                        acc[c] += (last ? run[a][c] : g) * z;
-                    }
-                }
+                for (int i = 0; i < N; ++i) sp += A[i][j] * pv[i];
+                pn[j] = sp;
             }
 #pragma unroll
-            for (int c = 0; c < M; ++c) {
-                if (!IN_M(c)) continue;
-                HERE(pf) = acc[c];
-                pf += stride;
+            for (int j = 0; j < N; ++j) {
+                pv[j] = pn[j];
+                if (k >= v - 1) ps[j] += pn[j];
+            }
+            if (k <= v - 1) {
+                char *pf = bf + (long long)k * m * stride;
+#pragma unroll
+                for (int c = 0; c < M; ++c) {
+                    if (!IN_M(c)) continue;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc += Bm[j][c] * (k == v - 1 ? ps[j] : pv[j]);
+                    HERE(pf) = acc;
+                    pf += stride;
+                }
             }
         }
     }
@@ -504,6 +513,21 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
         }
 #pragma unroll
         for (int bb = (STATIC ? V - 1 : bb_first); bb >= 0; --bb) {
+            // Q G_(f-1-bb), once per column: with the Markov blocks in LDS the compiler cannot tell their slots from the
+            // column buffer's and would read them again for every block of the column
+            double qgc[R][M];
+            if (!STATIC) {
+#pragma unroll
+                for (int a = 0; a < R; ++a)
+#pragma unroll
+                    for (int c = 0; c < M; ++c) {
+                        double sq = 0.0;
+#pragma unroll
+                        for (int q = 0; q < R; ++q)
+                            if (IN_R(q) && IN_M(c)) sq += Q[a][q] * LG(f - 1 - bb, q, c);
+                        qgc[a][c] = sq;
+                    }
+            }
 #pragma unroll
             for (int aa = 0; aa < (STATIC ? V : v); ++aa) {
                 double acc[M][M];
@@ -514,9 +538,13 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
 #pragma unroll
                         for (int c = 0; c < M; ++c) {
                             double sq = 0.0;
+                            if (STATIC) {
 #pragma unroll
-                            for (int q = 0; q < R; ++q)
-                                if (IN_R(q) && IN_M(c)) sq += Q[a][q] * LG(f - 1 - bb, q, c);
+                                for (int q = 0; q < R; ++q)
+                                    if (IN_R(q) && IN_M(c)) sq += Q[a][q] * LG(f - 1 - bb, q, c);
+                            } else {
+                                sq = qgc[a][c];
+                            }
                             qg[a][c] = sq;
                         }
 #pragma unroll

@@ -1,5 +1,5 @@
 # A/B of qp_lane variants (GPU box): bash tools/ab_lane.sh base <variant> ...   (alternating, two rounds)
-for a in "--f 32 --v 32" "--f 30 --v 10" "--f 8 --v 8" "--workload msd --f 32 --v 32 --batch 1048576"; do
+for a in "--f 20 --v 20 --steps 20" "--f 32 --v 32" "--f 30 --v 10" "--f 8 --v 8" "--workload msd --f 32 --v 32 --batch 1048576"; do
   for round in 1 2; do
     for lib in "$@"; do
       if [ "$lib" = base ]; then unset MPCX_LIB; else export MPCX_LIB=$PWD/build/exp/libmpcx_$lib.so; fi
