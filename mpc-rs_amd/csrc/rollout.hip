@@ -41,35 +41,57 @@ __global__ __launch_bounds__(kBlock) void rollout_lane_kernel(RolloutArgs p) {
 #pragma unroll
         for (int i = 0; i < N; ++i) IN(p.X, EX, i) = (T > 0) ? x[i] : 0.0;
     }
-    for (long long t = 0; t < T; ++t) {
-        double u[M];
+    // Eight steps at a time: their inputs are fetched first, the steps run in registers, and the 8 (N + R) outputs leave
+    // back to back (stores issued in bursts reach a higher write rate than stores spaced by the arithmetic that feeds
+    // them, and a per-instance input fetched inside a step would wait for every store issued before it).
+    constexpr int CH = 8;
+    for (long long t0 = 0; t0 < T; t0 += CH) {
+        const int steps = (int)(T - t0 < CH ? T - t0 : CH);  // wave-uniform
+        double u[CH][M], xs[CH][N], ys[CH][R];
 #pragma unroll
-        for (int k = 0; k < M; ++k) u[k] = p.u_shared ? p.U[t * M + k] : IN(p.U, EU, t * M + k);
-        if (p.Y) {
+        for (int q = 0; q < CH; ++q) {
+            const long long t = t0 + (q < steps ? q : steps - 1);
+#pragma unroll
+            for (int k = 0; k < M; ++k) u[q][k] = p.u_shared ? p.U[t * M + k] : IN(p.U, EU, t * M + k);
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            if (q >= steps) break;
 #pragma unroll
             for (int a = 0; a < R; ++a) {
                 double y = 0.0;
 #pragma unroll
                 for (int j = 0; j < N; ++j) y += Cm[a][j] * x[j];
-                IN(p.Y, EY, t * R + a) = y;
+                ys[q][a] = y;
+            }
+            double xn[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) s += A[i][j] * x[j];
+                double qq = 0.0;
+#pragma unroll
+                for (int k = 0; k < M; ++k) qq += Bm[i][k] * u[q][k];
+                xn[i] = s + qq;
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                x[i] = xn[i];
+                xs[q][i] = xn[i];
             }
         }
-        double xn[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double s = 0.0;
+        for (int q = 0; q < CH; ++q) {
+            if (q >= steps) break;
+            if (p.Y) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) s += A[i][j] * x[j];
-            double q = 0.0;
+                for (int a = 0; a < R; ++a) IN(p.Y, EY, (t0 + q) * R + a) = ys[q][a];
+            }
+            if (p.X) {
 #pragma unroll
-            for (int k = 0; k < M; ++k) q += Bm[i][k] * u[k];
-            xn[i] = s + q;
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = xn[i];
-        if (p.X) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) IN(p.X, EX, (t + 1) * N + i) = x[i];
+                for (int i = 0; i < N; ++i) IN(p.X, EX, (t0 + q + 1) * N + i) = xs[q][i];
+            }
         }
     }
 #undef IN
