@@ -190,8 +190,15 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
 #pragma unroll
             for (int j = 0; j < N; ++j) pphi[j] = bPhi + (long long)j * FR * stride;
         }
+        // (run-time horizons: four blocks are formed before they are stored, so that the stores leave back to back)
+        constexpr int kPB = STATIC ? 1 : 4;
 #pragma unroll
-        for (int i = 0; i < (STATIC ? F : f); ++i) {
+        for (int i0 = 0; i0 < (STATIC ? F : f); i0 += kPB) {
+          double Pb[kPB][R][N];
+#pragma unroll
+          for (int ub = 0; ub < kPB; ++ub) {
+            const int i = i0 + ub;
+            if (i >= f) break;
             double Pn[R][N];
 #pragma unroll
             for (int a = 0; a < R; ++a)
@@ -205,17 +212,10 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
-                for (int j = 0; j < N; ++j) P[a][j] = Pn[a][j];
-            if (wPhi) {
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-#pragma unroll
-                    for (int a = 0; a < R; ++a) {
-                        if (!(IN_N(j) && IN_R(a))) continue;
-                        HERE(pphi[j]) = P[a][j];
-                        pphi[j] += stride;
-                    }
-            }
+                for (int j = 0; j < N; ++j) {
+                    P[a][j] = Pn[a][j];
+                    Pb[ub][a][j] = Pn[a][j];
+                }
             if (wf) {
                 double s[R];
 #pragma unroll
@@ -233,6 +233,21 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                     if (IN_R(a)) LZ(i, a) = z;
                 }
             }
+          }
+          if (wPhi) {
+#pragma unroll
+            for (int ub = 0; ub < kPB; ++ub) {
+                if (i0 + ub >= f) break;
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+#pragma unroll
+                    for (int a = 0; a < R; ++a) {
+                        if (!(IN_N(j) && IN_R(a))) continue;
+                        HERE(pphi[j]) = Pb[ub][a][j];
+                        pphi[j] += stride;
+                    }
+            }
+          }
         }
     }
 
