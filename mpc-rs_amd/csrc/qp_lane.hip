@@ -30,6 +30,20 @@
 namespace mpcx {
 namespace {
 
+// Batch sizes of the run-time-horizon form (block rows of Gamma, elements of an H column, swept blocks, blocks of Phi
+// read or formed before their stores are issued)
+#ifndef MPCX_LANE_GB
+#define MPCX_LANE_GB 8
+#endif
+#ifndef MPCX_LANE_HB
+#define MPCX_LANE_HB 8
+#endif
+#ifndef MPCX_LANE_SB
+#define MPCX_LANE_SB 4
+#endif
+#ifndef MPCX_LANE_PB
+#define MPCX_LANE_PB 4
+#endif
 constexpr int kLaneBlock = 64;  // one wavefront per workgroup: LDS is carved per lane, no barriers needed
 
 // Returns x unchanged but opaque to the optimiser at this point, so that the zero-extension of the 32-bit lane
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
             for (int j = 0; j < N; ++j) pphi[j] = bPhi + (long long)j * FR * stride;
         }
         // (run-time horizons: four blocks are formed before they are stored, so that the stores leave back to back)
-        constexpr int kPB = STATIC ? 1 : 4;
+        constexpr int kPB = STATIC ? 1 : MPCX_LANE_PB;
 #pragma unroll
         for (int i0 = 0; i0 < (STATIC ? F : f); i0 += kPB) {
           double Pb[kPB][R][N];
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
     if (wGamma && !STATIC) {
         const unsigned lb = keep_local(lane_byte);
         char *pg = BASE(p.Gamma, (long long)FR * VM);
-        constexpr int kGB = 8;
+        constexpr int kGB = MPCX_LANE_GB;
         for (int k = 0; k < v; ++k) {
             const bool last = (k == v - 1);
 #pragma unroll
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
                 char *ph = bH + (long long)(bb * m + j) * VM * stride;
                 const double *w3 = gW3 + (long long)(bb * m + j) * VM;
                 if (!STATIC) {  // eight buffer reads, then eight stores (element e = aa m + i of the column sits in slot e m + j)
-                    constexpr int kHB = 8;
+                    constexpr int kHB = MPCX_LANE_HB;
                     int e = 0;
                     for (; e + kHB <= VM; e += kHB) {
                         double hv[kHB];
@@ -613,7 +627,7 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
             // Markov blocks go out together, one LDS round trip per four blocks instead of one per block
             int aa0 = 0;
             if (!STATIC && bb <= v - 3) {
-                constexpr int kSB = 4;
+                constexpr int kSB = MPCX_LANE_SB;
                 for (; aa0 + kSB <= v - 2; aa0 += kSB) {
                     double t[kSB][M][M], ga[kSB][R][M];
 #pragma unroll
