@@ -424,6 +424,189 @@ __global__ __launch_bounds__(kBlock, (NP <= 12 && MB <= 4) ? (SHU ? 4 : 3) : 1) 
 #undef IN
 }
 
+constexpr int kQuadStage = 192;  // steps of the shared input sequence staged in LDS at a time (a multiple of kChunk)
+static_assert(kQuadStage % kChunk == 0, "whole chunks");
+// FOUR lanes per instance (sixteen instances per wavefront) for instance-major batches of plants with n, r <= 4 RP
+// states / outputs, m <= 4 inputs and a shared input sequence.  Lane pp of a quad owns state rows and output rows
+// RP pp .. RP pp + RP - 1 with their rows of A, B, C in registers; the state is exchanged inside the quad with
+// data-parallel-primitive moves (quad_perm broadcasts), so a step is multiply-adds and register moves only: no LDS
+// access, no barrier and no idle lane on the serial path (the 16-lane form spends six LDS reads per lane and step on
+// state that every lane of a group reads again, and is bound by that round trip).  The outputs of a chunk of kChunk
+// steps stay in registers, go to the same per-instance LDS rings as in the 16-lane form afterwards and are flushed by
+// the same line-aligned paired stores, 16 lanes per instance, four instances per pass.
+template <int RP, bool HX, bool HY>
+__global__ __launch_bounds__(kBlock) void rollout_quad_kernel(RolloutArgs p) {
+    extern __shared__ double lds[];
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int NP = 4 * RP, MB = 4, IPW = kBlock / 4, G = 16;
+    constexpr int RS = ring_size(kChunk * NP + 16 + G);  // a chunk, the part of a line that waits, the flush's overshoot
+    constexpr int per_inst = 2 * RS + 2;                 // rings of X and Y, a spare entry for the rows a plant does not have
+    const int lane = threadIdx.x, qi = lane >> 2, pp = lane & 3;
+    const int n = p.n, m = p.m, r = p.r;
+    const long long T = p.T, EX = (long long)n * (T + 1), EY = (long long)r * T;
+    long long b = (long long)blockIdx.x * IPW + qi;
+    if (b >= p.batch) b = p.batch - 1;  // idle quads shadow the last instance (same values to the same addresses)
+    double rA[RP][NP], rC[RP][NP], rB[RP][MB], xo[RP];
+    {
+        const double *Ab = p.A + b * n * n, *Bb = p.B + b * n * m, *Cb = p.C + b * r * n, *x0b = p.x0 + b * n;
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const int row = RP * pp + j;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                rA[j][c] = (row < n && c < n) ? Ab[c * n + row] : 0.0;
+                rC[j][c] = (row < r && c < n) ? Cb[c * r + row] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < MB; ++k) rB[j][k] = (row < n && k < m) ? Bb[k * n + row] : 0.0;
+            xo[j] = row < n ? x0b[row] : 0.0;
+            // simulator.rs:13-17: X is zero-initialised and x0 is copied inside the loop, so T = 0 leaves column 0 zero
+            if (HX && row < n) p.X[b * EX + row] = (T > 0) ? xo[j] : 0.0;
+        }
+    }
+    // the shared input sequence, padded to four inputs per step, is staged in LDS kQuadStage steps at a time
+    double *sU = lds + (size_t)IPW * per_inst;
+    // Streams of the instance this lane computes for ("aligned coordinate" = element index + offset of the row start within
+    // its 128-byte line, as in the 16-lane form) ...
+    const int misx = HX ? (int)(((uintptr_t)(p.X + b * EX) >> 3) & 15) : 0;
+    const int misy = HY ? (int)(((uintptr_t)(p.Y + b * EY) >> 3) & 15) : 0;
+    double *ringX = lds + (size_t)qi * per_inst, *ringY = ringX + RS;
+    // ... and, at flush time, of the four instances whose pairs it stores (instance 4 ig + lane / 16 of the wavefront,
+    // pair lane % 16)
+    const int i = lane & 15;
+    // ring offsets of this lane's rows (a row beyond n or r goes to the spare entry behind the rings)
+    int offx[RP], offy[RP];
+    bool okx[RP], oky[RP];
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        const int row = RP * pp + j;
+        okx[j] = HX && row < n;
+        oky[j] = HY && row < r;
+        offx[j] = misx + row;
+        offy[j] = misy + row;
+    }
+    auto chunk = [&](const long long t0) {
+        const int steps = (int)((T - t0 < kChunk) ? T - t0 : kChunk);
+        if (t0 % kQuadStage == 0) {  // (a multiple of kChunk; the previous chunk's flush has ended with a barrier)
+            const long long cnt = ((T - t0 < kQuadStage) ? T - t0 : kQuadStage) * MB;
+            for (long long idx = lane; idx < cnt; idx += kBlock) {
+                const long long t = idx / MB;
+                const int k = (int)(idx - t * MB);
+                sU[idx] = k < m ? p.U[(t0 + t) * m + k] : 0.0;
+            }
+            lds_barrier();
+        }
+        const double *sUc = sU + (t0 % kQuadStage) * MB;
+        const int basex = ((int)t0 + 1) * n, basey = (int)t0 * r;
+#pragma unroll
+        for (int q = 0; q < kChunk; ++q) {
+            if (q >= steps) break;  // uniform
+            // ring position of this lane's first row in this step (formed here, not ahead of the chunk: kept opaque, the
+            // optimiser would otherwise carry one address per step, row and output through the whole chunk)
+            int cxq = basex + q * n + offx[0], cyq = basey + q * r + offy[0];
+            asm volatile("" : "+v"(cxq), "+v"(cyq));
+            // the step's input: one broadcast read of the staged sequence, issued ahead of the multiply-adds that hide it
+            double uq[MB];
+            {
+                const v2d u01 = *(const v2d *)(sUc + q * MB), u23 = *(const v2d *)(sUc + q * MB + 2);
+                uq[0] = u01.x;
+                uq[1] = u01.y;
+                uq[2] = u23.x;
+                uq[3] = u23.y;
+            }
+            double xf[NP];  // the whole state, gathered from the quad
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                xf[j] = dpp_f64<0x00>(xo[j]);
+                xf[RP + j] = dpp_f64<0x55>(xo[j]);
+                xf[2 * RP + j] = dpp_f64<0xAA>(xo[j]);
+                xf[3 * RP + j] = dpp_f64<0xFF>(xo[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                double s0 = 0.0, s1 = 0.0, y0 = 0.0, y1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < NP; c += 2) {
+                    s0 += rA[j][c] * xf[c];
+                    s1 += rA[j][c + 1] * xf[c + 1];
+                    if (HY) {
+                        y0 += rC[j][c] * xf[c];
+                        y1 += rC[j][c + 1] * xf[c + 1];
+                    }
+                }
+                double bu = 0.0;
+#pragma unroll
+                for (int k = 0; k < MB; ++k) bu += rB[j][k] * uq[k];
+                xo[j] = (s0 + s1) + bu;
+                // into the rings of this lane's instance: fire and forget, nothing on the serial path reads them
+                if (HX) ringX[okx[j] ? ((cxq + j) & (RS - 1)) : 2 * RS] = xo[j];
+                if (HY) ringY[oky[j] ? ((cyq + j) & (RS - 1)) : RS] = y0 + y1;
+            }
+            // (steps are not interleaved by the scheduler: what one step keeps live is all a step needs)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier();
+        // flush: up to the last 128-byte line boundary each row has reached; the first and the last flush of a row mask
+        // by element (see the 16-lane form)
+        const bool last = t0 + steps >= T;
+        const bool edge = last || t0 == 0;  // wave-uniform
+#pragma unroll
+        for (int ig = 0; ig < 4; ++ig) {
+            const double *sOut = lds + (size_t)(ig * 4 + (lane >> 4)) * per_inst;
+            long long bf = (long long)blockIdx.x * IPW + ig * 4 + (lane >> 4);
+            if (bf >= p.batch) bf = p.batch - 1;
+            double *bx = HX ? p.X + bf * EX : nullptr, *by = HY ? p.Y + bf * EY : nullptr;
+            const int fmx = (int)(((uintptr_t)bx >> 3) & 15), fmy = (int)(((uintptr_t)by >> 3) & 15);
+            double *rowx = bx - fmx, *rowy = by - fmy;
+            const int prodx = ((int)t0 + 1) * n + fmx, prody = (int)t0 * r + fmy;
+            const int ax = prodx & ~15, ay = prody & ~15;  // first unflushed line of each row
+            const int fx = ax & (RS - 1), fy = ay & (RS - 1);
+            if (edge) {
+                constexpr int NSTE = (kChunk * NP + 16 + 2 * G - 1) / (2 * G);  // one more line than a full chunk
+                const int endx = (int)EX + fmx, endy = (int)EY + fmy;
+                const int ax_new = last ? ((endx + 15) & ~15) : ((prodx + steps * n) & ~15);
+                const int ay_new = last ? ((endy + 15) & ~15) : ((prody + steps * r) & ~15);
+#pragma unroll
+                for (int k = 0; k < NSTE; ++k) {
+                    const int e2 = 2 * (i + k * G);
+                    if (HX) flush_pair_masked(rowx, sOut, ax + e2, fx + e2, RS, n + fmx, last ? endx : ax_new, ax_new);
+                    if (HY) flush_pair_masked(rowy, sOut + RS, ay + e2, fy + e2, RS, fmy, last ? endy : ay_new, ay_new);
+                }
+            } else {
+                constexpr int NST = (kChunk * NP + 2 * G - 1) / (2 * G);  // pair stores per lane and output
+                v2d vx[NST], vy[NST];
+#pragma unroll
+                for (int k = 0; k < NST; ++k) {
+                    const int e2 = 2 * (i + k * G);
+                    const int f = (fx + e2) & (RS - 1), h = (fy + e2) & (RS - 1);
+                    if (HX) vx[k] = *(const v2d *)(sOut + (e2 < kChunk * n ? f : 0));
+                    if (HY) vy[k] = *(const v2d *)(sOut + RS + (e2 < kChunk * r ? h : 0));
+                }
+#pragma unroll
+                for (int k = 0; k < NST; ++k) {
+                    const int e2 = 2 * (i + k * G);
+                    if (HX && e2 < kChunk * n) *(v2d *)(rowx + ax + e2) = vx[k];
+                    if (HY && e2 < kChunk * r) *(v2d *)(rowy + ay + e2) = vy[k];
+                }
+            }
+        }
+        lds_barrier();
+    };
+    for (long long t0 = 0; t0 < T; t0 += kChunk) chunk(t0);
+}
+
+template <int RP>
+int launch_quad(const RolloutArgs &a, hipStream_t s) {
+    constexpr int IPW = kBlock / 4, RS = ring_size(kChunk * 4 * RP + 16 + 16);
+    const long long blocks = (a.batch + IPW - 1) / IPW;
+    if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
+    const size_t lds_bytes = ((size_t)IPW * (2 * RS + 2) + (size_t)kQuadStage * 4) * sizeof(double);  // rings, staged inputs: 39 KB, four per CU
+    if (a.X && a.Y) hipLaunchKernelGGL((rollout_quad_kernel<RP, true, true>), dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, a);
+    else if (a.X) hipLaunchKernelGGL((rollout_quad_kernel<RP, true, false>), dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, a);
+    else hipLaunchKernelGGL((rollout_quad_kernel<RP, false, true>), dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, a);
+    return (int)hipGetLastError();
+}
+
 template <int G, int NP, int MB, bool HX, bool HY, bool SHU, bool FF>
 int launch_group_inst(const RolloutArgs &a, hipStream_t s) {
     constexpr int IPW = kBlock / G;
@@ -473,6 +656,19 @@ int launch_group_np(const RolloutArgs &a, hipStream_t s) {
 template <int G>
 int launch_group_one(const RolloutArgs &a, hipStream_t s) {
     if constexpr (G == 16) {
+#ifndef MPCX_RO_NO_QUAD  // (-DMPCX_RO_NO_QUAD: the 16-lane form everywhere, for comparison)
+        // instance-major, shared inputs, even row counts (the line-aligned paired flush): four lanes per instance
+        const bool short_rows = (long long)(a.n > a.r ? a.n : a.r) * (a.T + 2) < 0x7fffff00LL;
+        const bool ff = a.W == 1 && a.n % 2 == 0 && a.r % 2 == 0 && (((uintptr_t)a.X | (uintptr_t)a.Y) & 15) == 0 && short_rows;
+        // ... from about one round of the 16-lane form's resident wavefronts on (16 per CU x 4 instances x 256 CUs): a lone
+        // wavefront of the four-lane form takes longer per step (more instructions per lane), so small batches, which
+        // are bound by that latency, stay with sixteen lanes.  Quadrotor plants, T = 200, 16-lane / four-lane form:
+        // 2 048 instances 0.075 / 0.114 ms, 8 192 0.108 / 0.133, 16 384 0.186 / 0.165, 32 768 0.369 / 0.347 ms.
+        if (ff && a.u_shared && a.m <= 4 && (a.X || a.Y) && a.batch >= 12288) {
+            if (a.n <= 8 && a.r <= 8) return launch_quad<2>(a, s);
+            if (a.n <= 12 && a.r <= 12) return launch_quad<3>(a, s);
+        }
+#endif
         // NP also bounds the rows of Y the compact flush stores (NST pair stores cover kChunk NP doubles per output),
         // so the narrow instantiations need r <= NP as well as n <= NP
         if (a.m <= 4 && a.n <= 8 && a.r <= 8) return launch_group_np<16, 8, 4>(a, s);

@@ -58,6 +58,27 @@ def test_rollout_more_outputs_than_states(ctx, n, m, r, shared, interleave):
     assert_close(got["Y"], Y, f"n{n} m{m} r{r} shared={shared} W={interleave} Y")
 
 
+@pytest.mark.parametrize("n,m,r,T", [(12, 4, 12, 200), (12, 4, 12, 29), (10, 3, 8, 9), (8, 2, 6, 8), (6, 4, 8, 7), (2, 1, 2, 1),
+                                     (4, 2, 12, 17), (12, 1, 2, 401)])
+def test_rollout_four_lanes_per_instance(ctx, n, m, r, T):
+    """Large instance-major batches with a shared input sequence, even n, r <= 12 and m <= 4 take the kernel with four lanes
+    per instance (state exchanged inside the quad, inputs staged in LDS 192 steps at a time): ragged batch, T around the
+    8-step chunk and beyond one staging block, every plant different (simulator.rs:5-35)."""
+    rng = np.random.default_rng(9000 + n * 131 + m * 17 + r * 3 + T)
+    batch = 12288 + 5
+    A, B, C = random_stable_plants(rng, batch, n, m, r, rho=0.95)
+    x0 = rng.standard_normal((batch, n))
+    U = rng.standard_normal((m, T))
+    X, Y, _ = orc.rollout_batch(A, B, C, x0, U, threads=8)
+    got = ctx.rollout(A, B, C, x0, U, interleave=1)
+    assert_close(got["X"], X, f"n{n} m{m} r{r} T{T} X")
+    assert_close(got["Y"], Y, f"n{n} m{m} r{r} T{T} Y")
+    if T in (29, 9):  # one output alone: the same bits as in the full call
+        for k in ("X", "Y"):
+            part = ctx.rollout(A, B, C, x0, U, interleave=1, want=(k,))
+            assert np.array_equal(part[k], got[k]), f"{k} alone differs from the full call"
+
+
 def test_propagate_dynamics_is_rollout_with_T1(ctx):
     rng = np.random.default_rng(5)
     A, B, C = random_stable_plants(rng, 40, 4, 1, 1)
