@@ -22,7 +22,7 @@ CASES = {
     "qp_long_contract": (None, r"hessian_mfma_kernel"),
     "rollout_msd": ("rollout:msd:65536:20:20", r"rollout_lane_kernel"),
     "rollout_two_mass": ("rollout:two_mass:1048576:20:20", r"rollout_lane_kernel"),
-    "rollout_quadrotor": ("rollout:quadrotor:16384:50:50", r"rollout_group_kernel"),
+    "rollout_quadrotor": ("rollout:quadrotor:16384:50:50", r"rollout_group_kernel|rollout_quad_kernel"),
     "solve_two_mass": ("solve:two_mass:1048576:20:20", r"solve_rows2?_kernel"),
     "gain_two_mass": ("gain:two_mass:1048576:20:20", r"solve_rows2?_kernel"),
     "gain_rows_two_mass": ("gain_rows:two_mass:1048576:20:20", r"solve_rows2?_kernel|rows_lane_kernel|unit_columns_kernel"),
