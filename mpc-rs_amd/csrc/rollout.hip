@@ -439,8 +439,8 @@ __global__ __launch_bounds__(kBlock) void rollout_quad_kernel(RolloutArgs p) {
     extern __shared__ double lds[];
     typedef double v2d __attribute__((ext_vector_type(2)));
     constexpr int NP = 4 * RP, MB = 4, IPW = kBlock / 4, G = 16;
-    constexpr int RS = ring_size(kChunk * NP + 16 + G);  // a chunk, the part of a line that waits, the flush's overshoot
-    constexpr int per_inst = 2 * RS + 2;                 // rings of X and Y, a spare entry for the rows a plant does not have
+    constexpr int LB = ring_size(kChunk * NP + 16 + G);  // a chunk, the part of a line carried over, the edge flush's overshoot
+    constexpr int per_inst = 2 * LB;                     // staging buffers of X and Y
     const int lane = threadIdx.x, qi = lane >> 2, pp = lane & 3;
     const int n = p.n, m = p.m, r = p.r;
     const long long T = p.T, EX = (long long)n * (T + 1), EY = (long long)r * T;
@@ -467,24 +467,17 @@ __global__ __launch_bounds__(kBlock) void rollout_quad_kernel(RolloutArgs p) {
     // the shared input sequence, padded to four inputs per step, is staged in LDS kQuadStage steps at a time
     double *sU = lds + (size_t)IPW * per_inst;
     // Streams of the instance this lane computes for ("aligned coordinate" = element index + offset of the row start within
-    // its 128-byte line, as in the 16-lane form) ...
+    // its 128-byte line, as in the 16-lane form).  Each stream has a LINEAR staging buffer of LB entries per instance:
+    // entry 0 is the first unflushed line boundary of the row, the part of a line that a chunk leaves unflushed (fewer
+    // than 16 entries) is moved to the front before the next chunk, and a chunk's entries follow it.  No position wraps,
+    // so a step's stores are "base + step stride" with the lane's rows at immediate offsets; a lane whose row the plant
+    // does not have carries zero coefficients and writes a zero where the next step (later in program order) or the next
+    // chunk writes again, or beyond everything that is flushed.
     const int misx = HX ? (int)(((uintptr_t)(p.X + b * EX) >> 3) & 15) : 0;
     const int misy = HY ? (int)(((uintptr_t)(p.Y + b * EY) >> 3) & 15) : 0;
-    double *ringX = lds + (size_t)qi * per_inst, *ringY = ringX + RS;
-    // ... and, at flush time, of the four instances whose pairs it stores (instance 4 ig + lane / 16 of the wavefront,
-    // pair lane % 16)
+    const int bufX = qi * per_inst + RP * pp, bufY = bufX + LB;  // offsets into lds[] (LDS addressing stays visible)
+    // at flush time a lane stores pairs of four other instances (instance 4 ig + lane / 16 of the wavefront, pair lane % 16)
     const int i = lane & 15;
-    // ring offsets of this lane's rows (a row beyond n or r goes to the spare entry behind the rings)
-    int offx[RP], offy[RP];
-    bool okx[RP], oky[RP];
-#pragma unroll
-    for (int j = 0; j < RP; ++j) {
-        const int row = RP * pp + j;
-        okx[j] = HX && row < n;
-        oky[j] = HY && row < r;
-        offx[j] = misx + row;
-        offy[j] = misy + row;
-    }
     auto chunk = [&](const long long t0) {
         const int steps = (int)((T - t0 < kChunk) ? T - t0 : kChunk);
         if (t0 % kQuadStage == 0) {  // (a multiple of kChunk; the previous chunk's flush has ended with a barrier)
@@ -497,14 +490,15 @@ __global__ __launch_bounds__(kBlock) void rollout_quad_kernel(RolloutArgs p) {
             lds_barrier();
         }
         const double *sUc = sU + (t0 % kQuadStage) * MB;
-        const int basex = ((int)t0 + 1) * n, basey = (int)t0 * r;
+        // where this chunk's first step lands: behind the entries carried over from the previous chunk
+        const int wx = bufX + ((((int)t0 + 1) * n + misx) & 15), wy = bufY + (((int)t0 * r + misy) & 15);
 #pragma unroll
         for (int q = 0; q < kChunk; ++q) {
             if (q >= steps) break;  // uniform
-            // ring position of this lane's first row in this step (formed here, not ahead of the chunk: kept opaque, the
-            // optimiser would otherwise carry one address per step, row and output through the whole chunk)
-            int cxq = basex + q * n + offx[0], cyq = basey + q * r + offy[0];
-            asm volatile("" : "+v"(cxq), "+v"(cyq));
+            // (formed here and kept opaque: the optimiser would otherwise carry one address per step and output through
+            // the whole chunk)
+            int wxq = wx + q * n, wyq = wy + q * r;
+            asm volatile("" : "+v"(wxq), "+v"(wyq));
             // the step's input: one broadcast read of the staged sequence, issued ahead of the multiply-adds that hide it
             double uq[MB];
             {
@@ -538,39 +532,39 @@ __global__ __launch_bounds__(kBlock) void rollout_quad_kernel(RolloutArgs p) {
 #pragma unroll
                 for (int k = 0; k < MB; ++k) bu += rB[j][k] * uq[k];
                 xo[j] = (s0 + s1) + bu;
-                // into the rings of this lane's instance: fire and forget, nothing on the serial path reads them
-                if (HX) ringX[okx[j] ? ((cxq + j) & (RS - 1)) : 2 * RS] = xo[j];
-                if (HY) ringY[oky[j] ? ((cyq + j) & (RS - 1)) : RS] = y0 + y1;
+                // into the staging buffers of this lane's instance: fire and forget, nothing on the serial path reads them
+                if (HX) lds[wxq + j] = xo[j];
+                if (HY) lds[wyq + j] = y0 + y1;
             }
             // (steps are not interleaved by the scheduler: what one step keeps live is all a step needs)
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();
         // flush: up to the last 128-byte line boundary each row has reached; the first and the last flush of a row mask
-        // by element (see the 16-lane form)
+        // by element (see the 16-lane form); what lies beyond the boundary moves to the front of the buffer
         const bool last = t0 + steps >= T;
         const bool edge = last || t0 == 0;  // wave-uniform
 #pragma unroll
         for (int ig = 0; ig < 4; ++ig) {
-            const double *sOut = lds + (size_t)(ig * 4 + (lane >> 4)) * per_inst;
+            double *sOut = lds + (size_t)(ig * 4 + (lane >> 4)) * per_inst;
             long long bf = (long long)blockIdx.x * IPW + ig * 4 + (lane >> 4);
             if (bf >= p.batch) bf = p.batch - 1;
             double *bx = HX ? p.X + bf * EX : nullptr, *by = HY ? p.Y + bf * EY : nullptr;
             const int fmx = (int)(((uintptr_t)bx >> 3) & 15), fmy = (int)(((uintptr_t)by >> 3) & 15);
             double *rowx = bx - fmx, *rowy = by - fmy;
             const int prodx = ((int)t0 + 1) * n + fmx, prody = (int)t0 * r + fmy;
-            const int ax = prodx & ~15, ay = prody & ~15;  // first unflushed line of each row
-            const int fx = ax & (RS - 1), fy = ay & (RS - 1);
+            const int ax = prodx & ~15, ay = prody & ~15;  // first unflushed line of each row = entry 0 of its buffer
+            const int lx = ((prodx & 15) + steps * n) & ~15, ly = ((prody & 15) + steps * r) & ~15;  // entries flushed now
             if (edge) {
                 constexpr int NSTE = (kChunk * NP + 16 + 2 * G - 1) / (2 * G);  // one more line than a full chunk
                 const int endx = (int)EX + fmx, endy = (int)EY + fmy;
-                const int ax_new = last ? ((endx + 15) & ~15) : ((prodx + steps * n) & ~15);
-                const int ay_new = last ? ((endy + 15) & ~15) : ((prody + steps * r) & ~15);
+                const int ax_new = last ? ((endx + 15) & ~15) : ax + lx;
+                const int ay_new = last ? ((endy + 15) & ~15) : ay + ly;
 #pragma unroll
                 for (int k = 0; k < NSTE; ++k) {
                     const int e2 = 2 * (i + k * G);
-                    if (HX) flush_pair_masked(rowx, sOut, ax + e2, fx + e2, RS, n + fmx, last ? endx : ax_new, ax_new);
-                    if (HY) flush_pair_masked(rowy, sOut + RS, ay + e2, fy + e2, RS, fmy, last ? endy : ay_new, ay_new);
+                    if (HX) flush_pair_masked(rowx, sOut, ax + e2, e2, LB, n + fmx, last ? endx : ax_new, ax_new);
+                    if (HY) flush_pair_masked(rowy, sOut + LB, ay + e2, e2, LB, fmy, last ? endy : ay_new, ay_new);
                 }
             } else {
                 constexpr int NST = (kChunk * NP + 2 * G - 1) / (2 * G);  // pair stores per lane and output
@@ -578,9 +572,8 @@ __global__ __launch_bounds__(kBlock) void rollout_quad_kernel(RolloutArgs p) {
 #pragma unroll
                 for (int k = 0; k < NST; ++k) {
                     const int e2 = 2 * (i + k * G);
-                    const int f = (fx + e2) & (RS - 1), h = (fy + e2) & (RS - 1);
-                    if (HX) vx[k] = *(const v2d *)(sOut + (e2 < kChunk * n ? f : 0));
-                    if (HY) vy[k] = *(const v2d *)(sOut + RS + (e2 < kChunk * r ? h : 0));
+                    if (HX) vx[k] = *(const v2d *)(sOut + (e2 < kChunk * n ? e2 : 0));
+                    if (HY) vy[k] = *(const v2d *)(sOut + LB + (e2 < kChunk * r ? e2 : 0));
                 }
 #pragma unroll
                 for (int k = 0; k < NST; ++k) {
@@ -588,6 +581,11 @@ __global__ __launch_bounds__(kBlock) void rollout_quad_kernel(RolloutArgs p) {
                     if (HX && e2 < kChunk * n) *(v2d *)(rowx + ax + e2) = vx[k];
                     if (HY && e2 < kChunk * r) *(v2d *)(rowy + ay + e2) = vy[k];
                 }
+            }
+            if (!last) {  // carry: the (fewer than 16) entries behind the flushed lines go to the front
+                const double cxv = HX ? sOut[lx + i] : 0.0, cyv = HY ? sOut[LB + ly + i] : 0.0;
+                if (HX) sOut[i] = cxv;
+                if (HY) sOut[LB + i] = cyv;
             }
         }
         lds_barrier();
@@ -597,10 +595,10 @@ __global__ __launch_bounds__(kBlock) void rollout_quad_kernel(RolloutArgs p) {
 
 template <int RP>
 int launch_quad(const RolloutArgs &a, hipStream_t s) {
-    constexpr int IPW = kBlock / 4, RS = ring_size(kChunk * 4 * RP + 16 + 16);
+    constexpr int IPW = kBlock / 4, LB = ring_size(kChunk * 4 * RP + 16 + 16);
     const long long blocks = (a.batch + IPW - 1) / IPW;
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
-    const size_t lds_bytes = ((size_t)IPW * (2 * RS + 2) + (size_t)kQuadStage * 4) * sizeof(double);  // rings, staged inputs: 39 KB, four per CU
+    const size_t lds_bytes = ((size_t)IPW * 2 * LB + (size_t)kQuadStage * 4) * sizeof(double);  // staging buffers, staged inputs: 38 KB, four per CU
     if (a.X && a.Y) hipLaunchKernelGGL((rollout_quad_kernel<RP, true, true>), dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, a);
     else if (a.X) hipLaunchKernelGGL((rollout_quad_kernel<RP, true, false>), dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, a);
     else hipLaunchKernelGGL((rollout_quad_kernel<RP, false, true>), dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, a);
