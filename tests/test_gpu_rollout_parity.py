@@ -59,7 +59,7 @@ def test_rollout_more_outputs_than_states(ctx, n, m, r, shared, interleave):
 
 
 @pytest.mark.parametrize("n,m,r,T", [(12, 4, 12, 200), (12, 4, 12, 29), (10, 3, 8, 9), (8, 2, 6, 8), (6, 4, 8, 7), (2, 1, 2, 1),
-                                     (4, 2, 12, 17), (12, 1, 2, 401)])
+                                     (4, 2, 12, 17), (12, 1, 2, 401), (12, 4, 12, 0), (6, 2, 4, 192), (8, 4, 8, 193)])
 def test_rollout_four_lanes_per_instance(ctx, n, m, r, T):
     """Large instance-major batches with a shared input sequence, even n, r <= 12 and m <= 4 take the kernel with four lanes
     per instance (state exchanged inside the quad, inputs staged in LDS 192 steps at a time): ragged batch, T around the
