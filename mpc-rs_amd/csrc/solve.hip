@@ -321,13 +321,15 @@ __device__ __forceinline__ void for_each_index(F &f, std::integer_sequence<int, 
     (f(std::integral_constant<int, K>{}), ...);
 }
 
+constexpr int kRowsIpb = 8;  // instances per workgroup of solve_rows_kernel (256 threads: 32 lanes per instance)
+
 template <int NR, int NRHS, int RR>
 __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb) {
     constexpr int G = 32, NC = NR + NRHS, NCP = (NC + 1) & ~1;
     constexpr int EH = NR * NR, ER = NR * NRHS, ES = EH > ER ? EH : ER;
     static_assert(NR <= G, "one row per lane of a 32-lane group");
     extern __shared__ __align__(16) double sm[];
-    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int tid = threadIdx.x;
     const int ldi = ipb | 1;                 // odd leading dimension of the staging area: [element][instance]
     double *stage = sm;
     double *pbuf = sm + (((size_t)ES * ldi + 1) & ~(size_t)1);  // pivot rows: [group][NCP]
@@ -345,20 +347,39 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
 
     // tr: the square matrix is staged transposed (element (row, col) lands where (col, row) would), so that the lanes'
     // reads of their rows below are the same conflict-free pattern either way
-    auto load = [&](const double *src, int E, bool tr) {
+    // All of a thread's loads go out before the first is used (a loop of load - store to LDS - load waits a memory round
+    // trip per element, a dozen in a row here); a slot beyond the array reads a valid address and is dropped.
+    auto load = [&](const double *src, auto Ec, bool tr) {
+        constexpr int E = decltype(Ec)::value;
         if (p.W > 1) {  // instance fastest
-            const int step = nthreads / ipb, inst = tid % ipb;
+            constexpr int STEP = 256 / kRowsIpb, IT = (E + STEP - 1) / STEP;
+            const int inst = tid % kRowsIpb, e0 = tid / kRowsIpb;
             const double *sp = src + elem_index(b0 + (inst < live ? inst : 0), 0, E, p.W);
-            if (inst < live)
-                for (int e = tid / ipb; e < E; e += step) {
-                    const int es = tr ? (e % NR) * NR + e / NR : e;
-                    stage[es * ldi + inst] = sp[(long long)e * p.W];
-                }
-        } else {        // instance-major: elements fastest
-            for (int t = tid; t < live * E; t += nthreads) {
-                const int inst = t / E, e = t - inst * E;
+            double tmp[IT];
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int e = e0 + k * STEP;
+                tmp[k] = sp[(long long)(e < E ? e : E - 1) * p.W];
+            }
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int e = e0 + k * STEP;
                 const int es = tr ? (e % NR) * NR + e / NR : e;
-                stage[es * ldi + inst] = src[(b0 + inst) * (long long)E + e];
+                if (inst < live && e < E) stage[es * ldi + inst] = tmp[k];
+            }
+        } else {        // instance-major: elements fastest
+            constexpr int IT = (kRowsIpb * E + 255) / 256;
+            double tmp[IT];
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int t = tid + k * 256, tc = t < live * E ? t : 0;
+                tmp[k] = src[b0 * (long long)E + tc];  // (instance inst, element e of it: t = inst E + e)
+            }
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int t = tid + k * 256, inst = t / E, e = t - inst * E;
+                const int es = tr ? (e % NR) * NR + e / NR : e;
+                if (t < live * E) stage[es * ldi + inst] = tmp[k];
             }
         }
     };
@@ -367,12 +388,12 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
     const int gi = g < ipb ? g : 0, ii = i < NR ? i : 0;
     double a[NC];
 
-    load(p.H, EH, p.transposed != 0);
+    load(p.H, std::integral_constant<int, EH>{}, p.transposed != 0);
     lds_barrier();
 #pragma unroll
     for (int j = 0; j < NR; ++j) a[j] = stage[(j * NR + ii) * ldi + gi];
     lds_barrier();
-    load(p.R, ER, false);
+    load(p.R, std::integral_constant<int, ER>{}, false);
     lds_barrier();
     if constexpr (RR == 0) {
 #pragma unroll
@@ -466,15 +487,34 @@ __global__ __launch_bounds__(256, 4) void solve_rows_kernel(SolveArgs p, int ipb
         if (p.info && i == 0) p.info[b0 + g] = failed ? 1 : 0;
     }
     lds_barrier();
+    // (the staged results are read first and stored back to back)
     if (p.W > 1) {
-        const int step = nthreads / ipb, inst = tid % ipb;
+        constexpr int STEP = 256 / kRowsIpb, IT = (ER + STEP - 1) / STEP;
+        const int inst = tid % kRowsIpb, e0 = tid / kRowsIpb;
         double *xp = p.X + elem_index(b0 + (inst < live ? inst : 0), 0, ER, p.W);
-        if (inst < live)
-            for (int e = tid / ipb; e < ER; e += step) xp[(long long)e * p.W] = stage[e * ldi + inst];
+        double tmp[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int e = e0 + k * STEP;
+            tmp[k] = stage[(e < ER ? e : ER - 1) * ldi + inst];
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int e = e0 + k * STEP;
+            if (inst < live && e < ER) xp[(long long)e * p.W] = tmp[k];
+        }
     } else {
-        for (int t = tid; t < live * ER; t += nthreads) {
-            const int inst = t / ER, e = t - inst * ER;
-            p.X[(b0 + inst) * (long long)ER + e] = stage[e * ldi + inst];
+        constexpr int IT = (kRowsIpb * ER + 255) / 256;
+        double tmp[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int t = tid + k * 256, tc = t < live * ER ? t : 0, inst = tc / ER, e = tc - inst * ER;
+            tmp[k] = stage[e * ldi + inst];
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int t = tid + k * 256;
+            if (t < live * ER) p.X[b0 * (long long)ER + t] = tmp[k];
         }
     }
 }
@@ -503,18 +543,37 @@ __global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p) {
     const bool act0 = g < live, act1 = g < live && i + G < NR;
     constexpr long long EH = (long long)NR * NR, ER = (long long)NR * NRHS;
 
-    // `count` elements of an array (E per instance) into the staging area, element `elem_of(idx)` at slot idx
-    auto load_piece = [&](const double *src, long long E, int count, auto elem_of) {
+    // `count` elements of an array (E per instance) into the staging area, element `elem_of(idx)` at slot idx; all of a
+    // thread's loads go out before the first is used (a slot beyond the piece reads element 0 and is dropped)
+    auto load_piece = [&](const double *src, long long E, auto count_c, auto elem_of) {
+        constexpr int count = decltype(count_c)::value;
         if (p.W > 1) {  // instance fastest: one access = the same element of the workgroup's 16 instances
-            const int inst = tid % IPB;
-            if (inst < live) {
-                const double *sp = src + elem_index(b0 + inst, 0, E, p.W);
-                for (int idx = tid / IPB; idx < count; idx += 256 / IPB) stage[idx * LDI + inst] = sp[(long long)elem_of(idx) * p.W];
+            constexpr int STEP = 256 / IPB, IT = (count + STEP - 1) / STEP;
+            const int inst = tid % IPB, i0 = tid / IPB;
+            const double *sp = src + elem_index(b0 + (inst < live ? inst : 0), 0, E, p.W);
+            double tmp[IT];
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int idx = i0 + k * STEP;
+                tmp[k] = sp[(long long)elem_of(idx < count ? idx : 0) * p.W];
+            }
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int idx = i0 + k * STEP;
+                if (inst < live && idx < count) stage[idx * LDI + inst] = tmp[k];
             }
         } else {
-            for (int t = tid; t < live * count; t += 256) {
-                const int inst = t / count, idx = t - inst * count;
-                stage[idx * LDI + inst] = src[(b0 + inst) * E + elem_of(idx)];
+            constexpr int IT = (IPB * count + 255) / 256;
+            double tmp[IT];
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int t = tid + k * 256, tc = t < live * count ? t : 0, inst = tc / count, idx = tc - inst * count;
+                tmp[k] = src[(b0 + inst) * E + elem_of(idx)];
+            }
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int t = tid + k * 256, inst = t / count, idx = t - inst * count;
+                if (t < live * count) stage[idx * LDI + inst] = tmp[k];
             }
         }
     };
@@ -523,7 +582,7 @@ __global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p) {
     const bool tr = p.transposed != 0;
     auto load_h = [&](auto cc) {
         constexpr int jc = decltype(cc)::value * CW, cw = NR - jc < CW ? NR - jc : CW;
-        load_piece(p.H, EH, cw * NR, [&](int idx) { const int j = jc + idx / NR, row = idx % NR; return tr ? row * NR + j : j * NR + row; });
+        load_piece(p.H, EH, std::integral_constant<int, cw * NR>{}, [&](int idx) { const int j = jc + idx / NR, row = idx % NR; return tr ? row * NR + j : j * NR + row; });
         lds_barrier();
 #pragma unroll
         for (int jj = 0; jj < cw; ++jj) {
@@ -537,7 +596,7 @@ __global__ __launch_bounds__(256) void solve_rows2_kernel(SolveArgs p) {
     auto load_r = [&](auto cc) {
         constexpr int c0 = decltype(cc)::value * CW, cw = NRHS - c0 < CW ? NRHS - c0 : CW;
         // right-hand side column c, row `row`: R[c NR + row], or Gamma[c][row] = R[row NRHS + c] (controller.rs:96, M^T W4)
-        load_piece(p.R, ER, cw * NR, [&](int idx) { const int c = c0 + idx / NR, row = idx % NR; return RR ? row * NRHS + c : c * NR + row; });
+        load_piece(p.R, ER, std::integral_constant<int, cw * NR>{}, [&](int idx) { const int c = c0 + idx / NR, row = idx % NR; return RR ? row * NRHS + c : c * NR + row; });
         lds_barrier();
 #pragma unroll
         for (int jj = 0; jj < cw; ++jj) {
@@ -666,7 +725,7 @@ int launch_rows2(const SolveArgs &a, hipStream_t s) {
 template <int NR, int NRHS, int RR>
 int launch_rows(const SolveArgs &a, hipStream_t s) {
     constexpr int NC = NR + NRHS, NCP = (NC + 1) & ~1, ES = NR * (NR > NRHS ? NR : NRHS);
-    const int ipb = 8;  // 64-byte runs in the interleaved layouts; measured: 4 and 16 instances are 2 % and 7 % slower
+    const int ipb = kRowsIpb;  // 64-byte runs in the interleaved layouts; measured: 4 and 16 instances are 2 % and 7 % slower
     const long long blocks = ((a.batch + ipb - 1) / ipb + 15) / 16 * 16;  // whole groups of 16: see the kernel's workgroup numbering
     if (blocks > 0x7fffffffLL) return MPCX_ERR_UNSUPPORTED;
     const size_t lds = ((((size_t)ES * (ipb | 1) + 1) & ~(size_t)1) + (size_t)ipb * NCP) * sizeof(double);
