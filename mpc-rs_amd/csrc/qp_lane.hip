@@ -144,14 +144,36 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
 #pragma unroll
         for (int i = 0; i < N; ++i)
             if (IN_N(i)) x0[i] = AT(bx, i);
+        if (STATIC || !LAG) {
 #pragma unroll
-        for (int i = 0; i < (STATIC ? F : f); ++i)
+            for (int i = 0; i < (STATIC ? F : f); ++i)
 #pragma unroll
-            for (int a = 0; a < R; ++a) {
-                if (!IN_R(a)) continue;
-                LZ(i, a) = HERE(br);
+                for (int a = 0; a < R; ++a) {
+                    if (!IN_R(a)) continue;
+                    LZ(i, a) = HERE(br);
+                    br += stride;
+                }
+        } else {
+            // held inputs: eight loads in flight at a time; the f r elements of ref are consecutive, slot zbase + e.  (The loop
+            // above waits a memory round trip per pair of elements.  Measured both ways on 2^20 two-mass plants: with held
+            // inputs, f = 30, v = 10, batching gains 7 % (0.98 -> 0.92 ms); with f = v it loses 1-2 % (f = 20: 1.392 -> 1.408
+            // ms, f = 32: 3.22 -> 3.29 ms) -- there the wavefronts' store phases are long and the slow prologue spreads
+            // them out in time.)
+            constexpr int kRB = 8;
+            int e = 0;
+            for (; e + kRB <= FR; e += kRB) {
+                double t[kRB];
+#pragma unroll
+                for (int u = 0; u < kRB; ++u) t[u] = *(const double *)(br + (long long)u * stride + lb);
+#pragma unroll
+                for (int u = 0; u < kRB; ++u) lds[(zbase + e + u) * kLaneBlock + tid] = t[u];
+                br += kRB * stride;
+            }
+            for (; e < FR; ++e) {
+                lds[(zbase + e) * kLaneBlock + tid] = HERE(br);
                 br += stride;
             }
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no load is left in flight once the stores start
 
