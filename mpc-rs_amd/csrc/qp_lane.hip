@@ -157,8 +157,8 @@ __global__ __launch_bounds__(kLaneBlock, (F > 0 ? 3 : 1)) void qp_lane_kernel(co
             // held inputs: eight loads in flight at a time; the f r elements of ref are consecutive, slot zbase + e.  (The loop
             // above waits a memory round trip per pair of elements.  Measured both ways on 2^20 two-mass plants: with held
             // inputs, f = 30, v = 10, batching gains 7 % (0.98 -> 0.92 ms); with f = v it loses 1-2 % (f = 20: 1.392 -> 1.408
-            // ms, f = 32: 3.22 -> 3.29 ms) -- there the wavefronts' store phases are long and the slow prologue spreads
-            // them out in time.)
+            // ms, f = 32: 3.22 -> 3.29 ms; delaying wavefronts on purpose, by a few microseconds according to their index,
+            // loses more, so the reason is not that the slow prologue spreads them out in time).)
             constexpr int kRB = 8;
             int e = 0;
             for (; e + kRB <= FR; e += kRB) {
